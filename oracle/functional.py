@@ -1,0 +1,176 @@
+"""Oracle geometry + losses (torch-CPU fp32, differentiable through autograd).
+
+Citations are to the reference repository (paths relative to its root); ``dpp.py`` =
+``depth_pose_prediction/depth_pose_prediction.py``.
+"""
+from typing import Dict, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+from torch import Tensor
+
+
+# ----------------------------------------------------------------------------- pose -> 4x4
+def rot_from_axisangle(axis_angle: Tensor) -> Tensor:
+    """depth_pose_prediction/utils.py:74-117.  axis_angle (B,1,3) -> (B,4,4)."""
+    angle = torch.norm(axis_angle, 2, 2, True)
+    axis = axis_angle / (angle + 1e-7)
+    ca, sa = torch.cos(angle), torch.sin(angle)
+    C = 1 - ca
+    x = axis[..., 0].unsqueeze(1)
+    y = axis[..., 1].unsqueeze(1)
+    z = axis[..., 2].unsqueeze(1)
+    xs, ys, zs = x * sa, y * sa, z * sa
+    xC, yC, zC = x * C, y * C, z * C
+    xyC, yzC, zxC = x * yC, y * zC, z * xC
+    rot = torch.zeros((axis_angle.shape[0], 4, 4), dtype=axis_angle.dtype)
+    rot[:, 0, 0] = torch.squeeze(x * xC + ca)
+    rot[:, 0, 1] = torch.squeeze(xyC - zs)
+    rot[:, 0, 2] = torch.squeeze(zxC + ys)
+    rot[:, 1, 0] = torch.squeeze(xyC + zs)
+    rot[:, 1, 1] = torch.squeeze(y * yC + ca)
+    rot[:, 1, 2] = torch.squeeze(yzC - xs)
+    rot[:, 2, 0] = torch.squeeze(zxC - ys)
+    rot[:, 2, 1] = torch.squeeze(yzC + xs)
+    rot[:, 2, 2] = torch.squeeze(z * zC + ca)
+    rot[:, 3, 3] = 1
+    return rot
+
+
+def get_translation_matrix(t: Tensor) -> Tensor:
+    """depth_pose_prediction/utils.py:58-71."""
+    T = torch.zeros(t.shape[0], 4, 4, dtype=t.dtype)
+    T[:, 0, 0] = 1
+    T[:, 1, 1] = 1
+    T[:, 2, 2] = 1
+    T[:, 3, 3] = 1
+    T[:, :3, 3, None] = t.contiguous().view(-1, 3, 1)
+    return T
+
+
+def transformation_from_parameters(axis_angle: Tensor, translation: Tensor,
+                                   invert: bool = False) -> Tensor:
+    """depth_pose_prediction/utils.py:34-55."""
+    R = rot_from_axisangle(axis_angle)
+    t = translation.clone()
+    if invert:
+        R = R.transpose(1, 2)
+        t = t * -1
+    T = get_translation_matrix(t)
+    return torch.matmul(R, T) if invert else torch.matmul(T, R)
+
+
+def disp_to_depth(disp: Tensor, min_depth: Optional[float], max_depth: Optional[float]) -> Tensor:
+    """depth_pose_prediction/utils.py:120-142."""
+    if min_depth is None and max_depth is None:
+        return 1 / disp
+    if max_depth is None:
+        return min_depth / disp
+    if min_depth is None:
+        raise ValueError('min_depth is None')
+    min_disp = 1 / max_depth
+    max_disp = 1 / min_depth
+    return 1 / (min_disp + (max_disp - min_disp) * disp)
+
+
+# ----------------------------------------------------------------------------- view synthesis
+def backproject(depth: Tensor, inv_K: Tensor) -> Tensor:
+    """networks/layers.py:51-79.  depth (B,1,H,W) -> homogeneous points (B,4,H*W)."""
+    B, _, H, W = depth.shape
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float32),
+                            torch.arange(W, dtype=torch.float32), indexing='ij')
+    ones = torch.ones(B, 1, H * W)
+    pix = torch.stack([xs.reshape(-1), ys.reshape(-1)], 0).unsqueeze(0).repeat(B, 1, 1)
+    pix = torch.cat([pix, ones], 1)
+    cam = torch.matmul(inv_K[:, :3, :3], pix)
+    cam = depth.view(B, 1, -1) * cam
+    return torch.cat([cam, ones], 1)
+
+
+def project(points: Tensor, K: Tensor, T: Tensor, H: int, W: int, eps: float = 1e-7) -> Tensor:
+    """networks/layers.py:82-104.  -> normalised sampling grid (B,H,W,2)."""
+    B = points.shape[0]
+    P = torch.matmul(K, T)[:, :3, :]
+    cam = torch.matmul(P, points)
+    pix = cam[:, :2, :] / (cam[:, 2, :].unsqueeze(1) + eps)
+    pix = pix.view(B, 2, H, W).permute(0, 2, 3, 1)
+    pix = torch.stack([pix[..., 0] / (W - 1), pix[..., 1] / (H - 1)], -1)
+    return (pix - 0.5) * 2
+
+
+def reconstruct(disp_s: Tensor, T: Dict[int, Tensor], K: Tensor, inv_K: Tensor,
+                src: Dict[int, Tensor], H: int, W: int, min_depth, max_depth
+                ) -> Tuple[Tensor, Dict[int, Tensor]]:
+    """dpp.py:986-1017 for one scale: bilinear-upsample disp, disp->depth, backproject,
+    project with scale-0 intrinsics, grid_sample the un-augmented scale-0 source frame."""
+    disp = F.interpolate(disp_s, [H, W], mode='bilinear', align_corners=False)
+    depth = disp_to_depth(disp, min_depth, max_depth)
+    pts = backproject(depth, inv_K)
+    warped = {}
+    for f in (-1, 1):
+        grid = project(pts, K, T[f], H, W)
+        warped[f] = F.grid_sample(src[f], grid, padding_mode='border', align_corners=True)
+    return depth, warped
+
+
+# ----------------------------------------------------------------------------- losses
+def ssim(x: Tensor, y: Tensor) -> Tensor:
+    """networks/layers.py:107-137."""
+    C1, C2 = 0.01**2, 0.03**2
+    x = F.pad(x, (1, 1, 1, 1), mode='reflect')
+    y = F.pad(y, (1, 1, 1, 1), mode='reflect')
+    mu_x = F.avg_pool2d(x, 3, 1)
+    mu_y = F.avg_pool2d(y, 3, 1)
+    sigma_x = F.avg_pool2d(x**2, 3, 1) - mu_x**2
+    sigma_y = F.avg_pool2d(y**2, 3, 1) - mu_y**2
+    sigma_xy = F.avg_pool2d(x * y, 3, 1) - mu_x * mu_y
+    n = (2 * mu_x * mu_y + C1) * (2 * sigma_xy + C2)
+    d = (mu_x**2 + mu_y**2 + C1) * (sigma_x + sigma_y + C2)
+    return torch.clamp((1 - n / d) / 2, 0, 1)
+
+
+def reprojection_loss(pred: Tensor, target: Tensor) -> Tensor:
+    """dpp.py:1178-1192."""
+    l1 = torch.abs(target - pred).mean(1, True)
+    return 0.85 * ssim(pred, target).mean(1, True) + 0.15 * l1
+
+
+def smooth_loss_reference(disp: Tensor, img: Tensor) -> Tensor:
+    """dpp.py:1148-1176 with the all-true mask of the adaptation config
+    (mask_dynamic=False, :1081-1084), INCLUDING the flattening quirk:
+    ``masked_select`` flattens the whole batch, so ``grad_disp_x[i, ...]`` is the single flat
+    element i (pixel (0,i) of sample 0), broadcast against the mask and averaged."""
+    gdx = torch.abs(disp[:, :, :, :-1] - disp[:, :, :, 1:])
+    gdy = torch.abs(disp[:, :, :-1, :] - disp[:, :, 1:, :])
+    gix = torch.mean(torch.abs(img[:, :, :, :-1] - img[:, :, :, 1:]), 1, keepdim=True)
+    giy = torch.mean(torch.abs(img[:, :, :-1, :] - img[:, :, 1:, :]), 1, keepdim=True)
+    gdx = (gdx * torch.exp(-gix)).reshape(-1)
+    gdy = (gdy * torch.exp(-giy)).reshape(-1)
+    B = disp.shape[0]
+    return torch.stack([gdx[i] + gdy[i] for i in range(B)])
+
+
+def smooth_loss_intended(disp: Tensor, img: Tensor) -> Tensor:
+    """The per-sample edge-aware smoothness the reference evidently meant (monodepth2);
+    opt-in only, never used for parity."""
+    gdx = torch.abs(disp[:, :, :, :-1] - disp[:, :, :, 1:])
+    gdy = torch.abs(disp[:, :, :-1, :] - disp[:, :, 1:, :])
+    gix = torch.mean(torch.abs(img[:, :, :, :-1] - img[:, :, :, 1:]), 1, keepdim=True)
+    giy = torch.mean(torch.abs(img[:, :, :-1, :] - img[:, :, 1:, :]), 1, keepdim=True)
+    gdx = gdx * torch.exp(-gix)
+    gdy = gdy * torch.exp(-giy)
+    return gdx.flatten(1).mean(1) + gdy.flatten(1).mean(1)
+
+
+def velocity_loss(trans_m1: Tensor, trans_p1: Tensor, dist0: Tensor, dist1: Tensor) -> Tensor:
+    """dpp.py:1125-1146: frame 0 pairs translation(0->-1) with relative_distance(0), frame 1
+    pairs translation(0->+1) with relative_distance(1); L1 in the promoted dtype
+    (relative_distance is float64), accumulated into an fp32 vector, /2."""
+    B = trans_m1.shape[0]
+    out = torch.zeros(B, dtype=torch.float32)
+    for pred_t, gt in ((trans_m1, dist0), (trans_p1, dist1)):
+        gt_d = torch.abs(gt).reshape(B)
+        pred_d = torch.linalg.norm(pred_t, dim=-1).reshape(B)
+        # in-place fp32 += fp64 computes in fp64 and rounds back to fp32 (dpp.py:1142)
+        out = (out.double() + F.l1_loss(pred_d.double(), gt_d.double(), reduction='none')).float()
+    return out / 2
