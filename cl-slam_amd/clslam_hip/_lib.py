@@ -1,0 +1,90 @@
+"""ctypes binding of include/clslam_hip.h.
+
+The product loads exactly one library: ``cl-slam_amd/lib/libclslam_hip.so`` built for gfx950 by
+``cl-slam_amd/csrc/build.py``.  There is NO CPU fallback: if the library is missing, or is not a
+device build, loading raises.  (The host-logic tests install the kernel sources compiled against
+the CPU emulator through ``install_library_for_tests``; nothing in the product calls that.)
+"""
+import ctypes as C
+from pathlib import Path
+from typing import Optional
+
+LIB_PATH = Path(__file__).resolve().parents[1] / 'lib' / 'libclslam_hip.so'
+
+OK = 0
+ACT_NONE, ACT_RELU, ACT_ELU = 0, 1, 2
+PAD_ZERO, PAD_REFLECT = 0, 1
+
+fptr = C.c_void_p
+i32 = C.c_int32
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [('src_a', fptr), ('src_b', fptr), ('weight', fptr), ('scale', fptr), ('shift', fptr),
+                ('residual', fptr), ('out', fptr),
+                ('batch', i32), ('in_h', i32), ('in_w', i32), ('ch_a', i32), ('ch_b', i32),
+                ('out_h', i32), ('out_w', i32), ('ch_out', i32),
+                ('ksize', i32), ('stride', i32), ('pad', i32), ('pad_mode', i32), ('upsample_a', i32),
+                ('act', i32), ('config', i32)]
+
+
+# name -> argtypes (restype is always int unless listed in _RESTYPES)
+_SIGNATURES = {
+    'clslam_version': [],
+    'clslam_is_device_build': [],
+    'clslam_conv2d': [C.POINTER(ConvDesc), C.c_void_p],
+}
+_RESTYPES = {'clslam_last_error': C.c_char_p}
+
+
+class ClslamError(RuntimeError):
+    pass
+
+
+class Library:
+    def __init__(self, path: Path, require_device: bool = True) -> None:
+        if not Path(path).exists():
+            raise ClslamError(
+                f'{path} not found: build it with `python cl-slam_amd/csrc/build.py` '
+                '(hipcc --offload-arch=gfx950). There is no CPU fallback for this path.')
+        self.path = Path(path)
+        self.cdll = C.CDLL(str(path))
+        self.cdll.clslam_last_error.restype = C.c_char_p
+        self.cdll.clslam_last_error.argtypes = []
+        for name, argtypes in _SIGNATURES.items():
+            fn = getattr(self.cdll, name)  # AttributeError if the symbol is not exported
+            fn.argtypes = argtypes
+            fn.restype = C.c_int
+        self.is_device = bool(self.cdll.clslam_is_device_build())
+        if require_device and not self.is_device:
+            raise ClslamError(f'{path} is not a gfx950 device build')
+
+    def call(self, name: str, *args) -> None:
+        rc = getattr(self.cdll, name)(*args)
+        if rc != OK:
+            raise ClslamError(f'{name} failed ({rc}): {self.cdll.clslam_last_error().decode()}')
+
+    @property
+    def device_type(self) -> str:
+        return 'cuda' if self.is_device else 'cpu'
+
+
+_LIB: Optional[Library] = None
+
+
+def get_lib() -> Library:
+    global _LIB
+    if _LIB is None:
+        _LIB = Library(LIB_PATH, require_device=True)
+    return _LIB
+
+
+def install_library_for_tests(path) -> Library:
+    """TESTS ONLY: bind the kernel sources compiled against tests/emu (CPU emulator)."""
+    global _LIB
+    _LIB = Library(Path(path), require_device=False)
+    return _LIB
+
+
+def exported_symbols():
+    return ['clslam_last_error'] + list(_SIGNATURES)

@@ -1,0 +1,66 @@
+#!/usr/bin/env python
+"""Build libclslam_hip.so for gfx950 from the HIP sources in this directory.
+
+    python cl-slam_amd/csrc/build.py [--force]
+
+hipcc cross-compiles without a GPU; objects are cached by source mtime.  The shared library is
+written IN-TREE (cl-slam_amd/lib/libclslam_hip.so) so it travels to the GPU box with the
+repository snapshot.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+CSRC = Path(__file__).resolve().parent
+ROOT = CSRC.parents[1]
+LIB_DIR = CSRC.parent / 'lib'
+OBJ_DIR = CSRC / 'build'
+HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-DCLSLAM_DEVICE_BUILD=1',
+         '-I', str(CSRC / 'include'), '-Wno-unused-result']
+
+
+def _deps_mtime() -> float:
+    hs = list(CSRC.glob('*.h')) + list((CSRC / 'include').rglob('*.h')) + [ROOT / 'include' / 'clslam_hip.h']
+    return max(h.stat().st_mtime for h in hs)
+
+
+def build(force: bool = False, verbose: bool = True) -> Path:
+    LIB_DIR.mkdir(exist_ok=True)
+    OBJ_DIR.mkdir(exist_ok=True)
+    srcs = sorted(CSRC.glob('*.hip'))
+    hdr_m = _deps_mtime()
+    jobs = []
+    for s in srcs:
+        o = OBJ_DIR / (s.stem + '.o')
+        if force or not o.exists() or o.stat().st_mtime < max(s.stat().st_mtime, hdr_m):
+            jobs.append((s, o))
+
+    def cc(job):
+        s, o = job
+        cmd = [HIPCC, *FLAGS, '-c', str(s), '-o', str(o)]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f'hipcc failed for {s.name}:\n{r.stderr[-4000:]}')
+        if verbose:
+            print(f'[hipcc] {s.name}', flush=True)
+        return o
+
+    with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
+        list(ex.map(cc, jobs))
+    lib = LIB_DIR / 'libclslam_hip.so'
+    objs = [str(OBJ_DIR / (s.stem + '.o')) for s in srcs]
+    if jobs or not lib.exists():
+        r = subprocess.run([HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', str(lib), *objs],
+                           capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f'link failed:\n{r.stderr[-4000:]}')
+        if verbose:
+            print(f'[link] {lib}', flush=True)
+    return lib
+
+
+if __name__ == '__main__':
+    build(force='--force' in sys.argv)

@@ -1,0 +1,282 @@
+// K3/K4/K5: fp32 implicit-GEMM convolution on the CDNA4 matrix cores.
+//
+//   out[m][n] = act( scale[n] * sum_{tap,c} G(m,tap,c) * W[n][tap][c] + shift[n] (+ residual[m][n]) )
+//
+// m = (b, oy, ox) output pixel, n = output channel, NHWC activations, OHWI weights.  The gather
+// G resolves, inside the A-operand loader, everything the reference does with separate ops:
+//   * zero padding (torchvision BasicBlock convs, pose decoder; reference resnet_encoder.py:118-125,
+//     pose_decoder.py:28-30), any stride,
+//   * ReflectionPad2d(1) (reference layers.py:39-48),
+//   * nearest 2x upsampling of source A and channel-concat with skip source B
+//     (reference depth_decoder.py:56-65),
+// and the epilogue fuses folded eval-mode BatchNorm (scale/shift), conv bias (shift), the residual
+// add and ReLU / ELU.  The same kernel computes data gradients (dgrad = conv with transposed,
+// flipped weights over a zero-padded domain; see conv_bwd.hip).
+//
+// Tiling: 256 threads = 4 wavefronts (2x2 or 4x1); block tile BM x BN, K chunk BK channels of one tap;
+// A/B chunks are staged global -> registers -> LDS (rows padded to BK+4 floats so the
+// ds_read_b128 fragment reads of 16 consecutive rows hit 16 distinct 4-bank slots), double
+// buffered with one barrier per chunk; each wave owns TM x TN MFMA tiles of MF x MF
+// (v_mfma_f32_32x32x2_f32 or v_mfma_f32_16x16x4_f32).  A lane's float4 LDS read supplies four
+// consecutive k-steps (k = 4*(lane/MF)+t), so no operand shuffling is needed.
+#include "common.h"
+
+namespace clslam {
+
+struct ConvK {
+    const float* __restrict__ src_a;
+    const float* __restrict__ src_b;
+    const float* __restrict__ wgt;
+    const float* __restrict__ scale;
+    const float* __restrict__ shift;
+    const float* __restrict__ residual;
+    float* __restrict__ out;
+    int B, Hi, Wi, Ca, Cb, Ho, Wo, Cout;
+    int ksize, stride, pad, pad_mode, ups, act;
+    int M, tilesM, tilesN, nblk;
+};
+
+template <int BM, int BN, int BK, int MF, int WGM>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvK p) {
+    constexpr int LDA = BK + 4;
+    constexpr int WGN = 4 / WGM;                  // wave grid WGM x WGN (4 waves)
+    constexpr int WM = BM / WGM, WN = BN / WGN;   // per-wave tile
+    constexpr int TM = WM / MF, TN = WN / MF;     // MFMA tiles per wave
+    constexpr int KG = 64 / MF;                   // k-groups inside a wave (2 for 32x32x2, 4 for 16x16x4)
+    constexpr int KSTEP = KG * 4;                 // k consumed per float4 fragment read
+    constexpr int F4_ROW = BK / 4;                // float4 per tile row
+    constexpr int A_IT = (BM * F4_ROW + 255) / 256;
+    constexpr int B_IT = (BN * F4_ROW + 255) / 256;
+    constexpr int NACC = MF == 32 ? 16 : 4;
+    static_assert(WM % MF == 0 && WN % MF == 0 && BK % KSTEP == 0, "tile shape");
+
+    __shared__ __attribute__((aligned(16))) float As[2][BM * LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BN * LDA];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm0 = (wave / WGN) * WM, wn0 = (wave % WGN) * WN;
+
+    const int logical = xcd_remap((int)blockIdx.x, p.nblk);
+    const int tn = logical / p.tilesM, tm = logical - tn * p.tilesM;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int Cin = p.Ca + p.Cb;
+    const int taps = p.ksize * p.ksize;
+    const int HA = p.ups ? (p.Hi >> 1) : p.Hi, WA = p.ups ? (p.Wi >> 1) : p.Wi;
+
+    // ---- per-thread A-load slots: fixed output pixel per slot --------------------------------
+    int a_b[A_IT], a_iy0[A_IT], a_ix0[A_IT];
+    bool a_ok[A_IT];
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+        const int f = tid + it * 256;
+        const int row = f / F4_ROW;
+        const int m = m0 + row;
+        a_ok[it] = (f < BM * F4_ROW) && (m < p.M);
+        const int mm = a_ok[it] ? m : 0;
+        const int b = mm / (p.Ho * p.Wo);
+        const int r = mm - b * (p.Ho * p.Wo);
+        const int oy = r / p.Wo, ox = r - oy * p.Wo;
+        a_b[it] = b;
+        a_iy0[it] = oy * p.stride - p.pad;
+        a_ix0[it] = ox * p.stride - p.pad;
+    }
+
+    float4 ra[A_IT], rb[B_IT];
+    const int chunks_per_tap = Cin / BK;
+    const int niter = taps * chunks_per_tap;
+
+    auto load_global = [&](int iter) {
+        const int tap = iter / chunks_per_tap;
+        const int c0 = (iter - tap * chunks_per_tap) * BK;
+        const int ky = tap / p.ksize, kx = tap - ky * p.ksize;
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            const int f = tid + it * 256;
+            const int c = c0 + (f % F4_ROW) * 4;
+            int iy = a_iy0[it] + ky, ix = a_ix0[it] + kx;
+            bool ok = a_ok[it];
+            if (p.pad_mode == CLSLAM_PAD_REFLECT) {
+                iy = reflect_idx(iy, p.Hi);
+                ix = reflect_idx(ix, p.Wi);
+            } else {
+                ok = ok && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
+            }
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok) {
+                const float* ptr;
+                if (c < p.Ca) {
+                    const int sy = p.ups ? (iy >> 1) : iy, sx = p.ups ? (ix >> 1) : ix;
+                    ptr = p.src_a + ((size_t)(a_b[it] * HA + sy) * WA + sx) * p.Ca + c;
+                } else {
+                    ptr = p.src_b + ((size_t)(a_b[it] * p.Hi + iy) * p.Wi + ix) * p.Cb + (c - p.Ca);
+                }
+                v = *reinterpret_cast<const float4*>(ptr);
+            }
+            ra[it] = v;
+        }
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it) {
+            const int f = tid + it * 256;
+            const int row = f / F4_ROW;
+            const int n = n0 + row;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (f < BN * F4_ROW && n < p.Cout)
+                v = *reinterpret_cast<const float4*>(p.wgt + ((size_t)n * taps + tap) * Cin + c0 + (f % F4_ROW) * 4);
+            rb[it] = v;
+        }
+    };
+    auto store_lds = [&](int buf) {
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            const int f = tid + it * 256;
+            if (f < BM * F4_ROW)
+                *reinterpret_cast<float4*>(&As[buf][(f / F4_ROW) * LDA + (f % F4_ROW) * 4]) = ra[it];
+        }
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it) {
+            const int f = tid + it * 256;
+            if (f < BN * F4_ROW)
+                *reinterpret_cast<float4*>(&Bs[buf][(f / F4_ROW) * LDA + (f % F4_ROW) * 4]) = rb[it];
+        }
+    };
+
+    typedef float accv __attribute__((ext_vector_type(NACC)));
+    accv acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < NACC; ++r) acc[i][j][r] = 0.f;
+
+    const int frow = lane % MF;        // row inside an MFMA tile this lane feeds
+    const int kg = lane / MF;          // k-group
+
+    load_global(0);
+    store_lds(0);
+    __syncthreads();
+
+    for (int iter = 0; iter < niter; ++iter) {
+        const int buf = iter & 1;
+        if (iter + 1 < niter) load_global(iter + 1);
+#pragma unroll
+        for (int kk = 0; kk < BK / KSTEP; ++kk) {
+            float4 fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                fa[i] = *reinterpret_cast<const float4*>(&As[buf][(wm0 + i * MF + frow) * LDA + kk * KSTEP + kg * 4]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                fb[j] = *reinterpret_cast<const float4*>(&Bs[buf][(wn0 + j * MF + frow) * LDA + kk * KSTEP + kg * 4]);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const float av = t == 0 ? fa[i].x : t == 1 ? fa[i].y : t == 2 ? fa[i].z : fa[i].w;
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const float bv = t == 0 ? fb[j].x : t == 1 ? fb[j].y : t == 2 ? fb[j].z : fb[j].w;
+                        if constexpr (MF == 32) acc[i][j] = mfma_32x32x2(av, bv, acc[i][j]);
+                        else acc[i][j] = mfma_16x16x4(av, bv, acc[i][j]);
+                    }
+                }
+            }
+        }
+        if (iter + 1 < niter) store_lds(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: BN/bias, residual, activation, NHWC store (lanes run along channels) ------
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn0 + j * MF + (lane % MF);
+            if (n >= p.Cout) continue;
+            const float sc = p.scale ? p.scale[n] : 1.f;
+            const float sh = p.shift ? p.shift[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < NACC; ++r) {
+                int row;
+                if constexpr (MF == 32) row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                else row = 4 * (lane >> 4) + r;
+                const int m = m0 + wm0 + i * MF + row;
+                if (m >= p.M) continue;
+                float v = acc[i][j][r] * sc + sh;
+                if (p.residual) v += p.residual[(size_t)m * p.Cout + n];
+                p.out[(size_t)m * p.Cout + n] = apply_act(v, p.act);
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int BK, int MF, int WGM>
+static int launch_conv(ConvK k, hipStream_t stream) {
+    k.tilesM = cdiv(k.M, BM);
+    k.tilesN = cdiv(k.Cout, BN);
+    k.nblk = k.tilesM * k.tilesN;
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, MF, WGM>), dim3(k.nblk), dim3(256), 0, stream, k);
+    return check_launch("conv_igemm");
+}
+
+}  // namespace clslam
+
+using namespace clslam;
+
+// Tile configurations (BM x BN x BK, MFMA shape, wave grid).  Chosen per layer by clslam_conv2d
+// when desc->config < 0; tests sweep them explicitly.
+//   0: 128x64x32  32x32x2  2x2 waves (2x1 tiles/wave)   large-M layers with Cout >= 64
+//   1:  64x64x32  32x32x2  2x2                           mid layers
+//   2:  32x32x32  16x16x4  2x2                           small-M layers (layer3/4, pose decoder)
+//   3:  64x32x32  16x16x4  2x2 (2x1 tiles/wave)          Cout == 32
+//   4: 128x16x16  16x16x4  4x1 (2x1 tiles/wave)          Cout == 16, Cin % 32 != 0
+//   5:  64x32x16  16x16x4  2x2                           BK = 16 fallback
+//   6: 128x16x32  16x16x4  4x1                           Cout == 16, Cin % 32 == 0
+extern "C" int clslam_conv2d(const clslam_conv_desc* d, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    CLSLAM_REQUIRE(d && d->src_a && d->weight && d->out, "conv2d: null pointer");
+    const int Cin = d->ch_a + d->ch_b;
+    CLSLAM_REQUIRE(d->ksize == 1 || d->ksize == 3, "conv2d: ksize %d unsupported", d->ksize);
+    CLSLAM_REQUIRE(Cin % 16 == 0 && d->ch_a % 16 == 0 && d->ch_out % 16 == 0,
+                   "conv2d: channels must be multiples of 16 (Ca=%d Cb=%d Cout=%d)", d->ch_a, d->ch_b, d->ch_out);
+    CLSLAM_REQUIRE(!d->upsample_a || (d->in_h % 2 == 0 && d->in_w % 2 == 0), "conv2d: upsample needs even dims");
+    CLSLAM_REQUIRE(d->pad_mode == CLSLAM_PAD_ZERO || (d->pad < d->in_h && d->pad < d->in_w), "conv2d: reflect pad too large");
+    CLSLAM_REQUIRE(d->ch_b == 0 || d->src_b, "conv2d: src_b missing");
+    ConvK k;
+    k.src_a = d->src_a; k.src_b = d->src_b; k.wgt = d->weight; k.scale = d->scale; k.shift = d->shift;
+    k.residual = d->residual; k.out = d->out;
+    k.B = d->batch; k.Hi = d->in_h; k.Wi = d->in_w; k.Ca = d->ch_a; k.Cb = d->ch_b;
+    k.Ho = d->out_h; k.Wo = d->out_w; k.Cout = d->ch_out;
+    k.ksize = d->ksize; k.stride = d->stride; k.pad = d->pad; k.pad_mode = d->pad_mode;
+    k.ups = d->upsample_a; k.act = d->act;
+    k.M = d->batch * d->out_h * d->out_w;
+    k.tilesM = k.tilesN = k.nblk = 0;
+    if (k.M == 0) return CLSLAM_OK;
+    int cfg = d->config;
+    const bool bk32 = (Cin % 32 == 0) && (d->ch_b == 0 || d->ch_a % 32 == 0);
+    if (cfg < 0) {
+        if (d->ch_out % 32 != 0) cfg = bk32 ? 6 : 4;
+        else if (!bk32) cfg = 5;
+        else if (d->ch_out == 32) cfg = 3;
+        else {
+            const long blocks0 = (long)cdiv(k.M, 128) * cdiv(d->ch_out, 64);
+            const long blocks1 = (long)cdiv(k.M, 64) * cdiv(d->ch_out, 64);
+            cfg = blocks0 >= 1024 ? 0 : (blocks1 >= 512 ? 1 : 2);
+        }
+    }
+    const bool need32 = (cfg <= 3 || cfg == 6);
+    if (need32 && !bk32) { set_error("conv2d: config %d needs channel multiples of 32", cfg); return CLSLAM_ERR_INVALID; }
+    if ((cfg == 0 || cfg == 1) && d->ch_out % 32 != 0) { set_error("conv2d: config %d needs Cout %% 32 == 0", cfg); return CLSLAM_ERR_INVALID; }
+    switch (cfg) {
+        case 0: return launch_conv<128, 64, 32, 32, 2>(k, stream);
+        case 1: return launch_conv<64, 64, 32, 32, 2>(k, stream);
+        case 2: return launch_conv<32, 32, 32, 16, 2>(k, stream);
+        case 3: return launch_conv<64, 32, 32, 16, 2>(k, stream);
+        case 4: return launch_conv<128, 16, 16, 16, 4>(k, stream);
+        case 5: return launch_conv<64, 32, 16, 16, 2>(k, stream);
+        case 6: return launch_conv<128, 16, 32, 16, 4>(k, stream);
+        default: set_error("conv2d: unknown config %d", cfg); return CLSLAM_ERR_INVALID;
+    }
+}

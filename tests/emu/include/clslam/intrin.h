@@ -1,0 +1,61 @@
+// EMULATED counterparts of cl-slam_amd/csrc/include/clslam/intrin.h (wave collectives and
+// MFMA), following the gfx950 operand layouts documented in cdna_hip_programming.md section 3:
+//   32x32x2 f32 : A[i=l&31][k=l>>5], B[k=l>>5][j=l&31]; D reg r -> row (r&3)+8*(r>>2)+4*(l>>5), col l&31
+//   16x16x4 f32 : A[i=l&15][k=l>>4], B[k=l>>4][j=l&15]; D reg r -> row 4*(l>>4)+r, col l&15
+// TEST INFRASTRUCTURE ONLY.
+#pragma once
+#include <hip/hip_runtime.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace clslam {
+
+constexpr int kWave = 64;
+inline int lane_id() { return (int)(threadIdx.x & 63); }
+
+inline f32x16 mfma_32x32x2(float a, float b, f32x16 c) {
+    const int l = lane_id();
+    float* s = emu_wave_scratch() + emu_wave_phase() * 128;
+    s[l] = a;
+    s[64 + l] = b;
+    emu_sync_wave();
+    const int j = l & 31, hi = l >> 5;
+    for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        float acc = c[r];
+        for (int k = 0; k < 2; ++k) acc = fmaf(s[k * 32 + i], s[64 + k * 32 + j], acc);
+        c[r] = acc;
+    }
+    return c;
+}
+
+inline f32x4 mfma_16x16x4(float a, float b, f32x4 c) {
+    const int l = lane_id();
+    float* s = emu_wave_scratch() + emu_wave_phase() * 128;
+    s[l] = a;
+    s[64 + l] = b;
+    emu_sync_wave();
+    const int j = l & 15, g = l >> 4;
+    for (int r = 0; r < 4; ++r) {
+        const int i = 4 * g + r;
+        float acc = c[r];
+        for (int k = 0; k < 4; ++k) acc = fmaf(s[k * 16 + i], s[64 + k * 16 + j], acc);
+        c[r] = acc;
+    }
+    return c;
+}
+
+// butterfly all-reduce over the 64 lanes of a wave (same pairing order as the HIP version)
+inline float wave_sum(float v) {
+    const int l = lane_id();
+    for (int off = 32; off >= 1; off >>= 1) {
+        float* s = emu_wave_scratch() + emu_wave_phase() * 128;
+        s[l] = v;
+        emu_sync_wave();
+        v = v + s[l ^ off];
+    }
+    return v;
+}
+
+}  // namespace clslam
