@@ -25,7 +25,7 @@ class ConvDesc(C.Structure):
                 ('batch', i32), ('in_h', i32), ('in_w', i32), ('ch_a', i32), ('ch_b', i32),
                 ('out_h', i32), ('out_w', i32), ('ch_out', i32),
                 ('ksize', i32), ('stride', i32), ('pad', i32), ('pad_mode', i32), ('upsample_a', i32),
-                ('act', i32), ('config', i32)]
+                ('act', i32), ('config', i32), ('actgrad_src', fptr), ('actgrad_kind', i32)]
 
 
 # name -> argtypes (restype is always int unless listed in _RESTYPES)
@@ -33,6 +33,13 @@ _SIGNATURES = {
     'clslam_version': [],
     'clslam_is_device_build': [],
     'clslam_conv2d': [C.POINTER(ConvDesc), C.c_void_p],
+    'clslam_weight_transpose': [fptr, fptr, i32, i32, i32, i32, C.c_void_p],
+    'clslam_fold_act_grad': [fptr, fptr, fptr, i32, i32, i32, i32, i32, i32, i32, i32, C.c_void_p],
+    'clslam_wgrad_splits': [C.POINTER(ConvDesc), i32],
+    'clslam_conv_wgrad': [C.POINTER(ConvDesc), fptr, fptr, i32, C.c_void_p],
+    'clslam_reduce_partials': [fptr, fptr, C.c_size_t, i32, C.c_float, C.c_void_p],
+    'clslam_colsum_blocks': [i32],
+    'clslam_colsum': [fptr, fptr, i32, i32, C.c_void_p],
 }
 _RESTYPES = {'clslam_last_error': C.c_char_p}
 

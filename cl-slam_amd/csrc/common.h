@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <clslam/intrin.h>
 
+#include <algorithm>
+
 #include "../../include/clslam_hip.h"
 
 namespace clslam {

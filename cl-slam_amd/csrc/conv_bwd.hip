@@ -1,0 +1,363 @@
+// K15/K17: backward of the trainable convolutions (depth decoder, pose decoder).
+// The reference gets these from autograd of networks/depth_decoder.py:51-71,
+// networks/layers.py:9-48 and networks/pose_decoder.py:37-54 (cuDNN convolution_backward,
+// reflection_pad2d_backward, upsample_nearest2d_backward, elu_backward, cat backward).
+//
+//   dgrad : clslam_weight_transpose + clslam_conv2d on the zero-padded (H+2)x(W+2) domain
+//           (pad = 2) gives d(padded input); clslam_fold_act_grad folds the reflection border
+//           back, sums the 2x2 nearest-upsample footprint and multiplies by act'(y).
+//   wgrad : dW[n][tap][c] = sum_m dZ[m][n] * G(m,tap,c) as an MFMA GEMM whose reduction axis is
+//           the pixel index m; split over pixel ranges (deterministic two-stage reduction:
+//           clslam_wgrad writes per-split partials, clslam_reduce_partials sums them in order).
+//   bias  : clslam_colsum (two-stage, deterministic).
+#include "common.h"
+
+namespace clslam {
+
+// ------------------------------------------------------------------------------------------------
+__global__ void weight_transpose_kernel(const float* __restrict__ w, float* __restrict__ wt, int Cout,
+                                        int taps, int Cin, int CinSel) {
+    // wt[ci][taps-1-t][co] = w[co][t][ci]
+    const int total = CinSel * taps * Cout;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int co = i % Cout;
+        const int t2 = (i / Cout) % taps;
+        const int ci = i / (Cout * taps);
+        wt[i] = w[((size_t)co * taps + (taps - 1 - t2)) * Cin + ci];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// dz[b,y,x,c] = act'(yout[b,y,x,c]) * sum_{(Y,X) in footprint(y,x)} sum_{P -> (Y,X)} dxp[b,P,c]
+__global__ void fold_act_grad_kernel(const float* __restrict__ dxp, const float* __restrict__ yout,
+                                     float* __restrict__ dz, int B, int H, int W, int C, int e, int pool,
+                                     int act, int Cp) {
+    // H, W: resolution of the conv input whose padded-domain gradient dxp [(H+2e)][(W+2e)][Cp] holds;
+    // output resolution is (H,W) or (H/2,W/2) when pool; only channels [0,C) are consumed.
+    const int Ho = pool ? H / 2 : H, Wo = pool ? W / 2 : W;
+    const int C4 = C / 4;
+    const int Hp = H + 2 * e, Wp = W + 2 * e;
+    const size_t total = (size_t)B * Ho * Wo * C4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        const int x = (int)((i / C4) % Wo);
+        const int y = (int)((i / ((size_t)C4 * Wo)) % Ho);
+        const int b = (int)(i / ((size_t)C4 * Wo * Ho));
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int ny = pool ? 2 : 1;
+        for (int dy = 0; dy < ny; ++dy) {
+            for (int dx = 0; dx < ny; ++dx) {
+                const int Y = pool ? 2 * y + dy : y, X = pool ? 2 * x + dx : x;
+                int py[3], px[3];
+                int npy = 0, npx = 0;
+                py[npy++] = Y + e;
+                px[npx++] = X + e;
+                if (e) {
+                    if (Y == 1) py[npy++] = 0;
+                    if (Y == H - 2) py[npy++] = H + 1;
+                    if (X == 1) px[npx++] = 0;
+                    if (X == W - 2) px[npx++] = W + 1;
+                }
+                for (int a = 0; a < npy; ++a)
+                    for (int q = 0; q < npx; ++q) {
+                        const float4 v = *reinterpret_cast<const float4*>(
+                            dxp + ((size_t)(b * Hp + py[a]) * Wp + px[q]) * Cp + c4 * 4);
+                        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+                    }
+            }
+        }
+        const size_t o = ((size_t)(b * Ho + y) * Wo + x) * C + c4 * 4;
+        if (yout) {
+            const float4 yv = *reinterpret_cast<const float4*>(yout + o);
+            acc.x *= act_grad_from_output(yv.x, act);
+            acc.y *= act_grad_from_output(yv.y, act);
+            acc.z *= act_grad_from_output(yv.z, act);
+            acc.w *= act_grad_from_output(yv.w, act);
+        }
+        *reinterpret_cast<float4*>(dz + o) = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+struct WgradK {
+    const float* __restrict__ dz;
+    const float* __restrict__ src_a;
+    const float* __restrict__ src_b;
+    float* __restrict__ partial;
+    int B, Hi, Wi, Ca, Cb, Ho, Wo, Cout;
+    int ksize, stride, pad, pad_mode, ups;
+    int M, chunks_per_split, co_tiles, ci_tiles, tap_groups;
+};
+
+template <int COT, int CIT, int NT, int MF>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradK p) {
+    constexpr int KM = 32;                       // pixels per chunk
+    constexpr int LDZ = COT + 4, LDG = CIT + 4;  // float4-aligned rows
+    constexpr int TI = COT / MF, TJ = CIT / MF;
+    constexpr int NTILES = TI * TJ * NT;
+    constexpr int TPW = (NTILES + 3) / 4;        // MFMA tiles per wave
+    constexpr int NACC = MF == 32 ? 16 : 4;
+    constexpr int KG = 64 / MF;                  // pixel rows consumed per MFMA
+    constexpr int Z_F4 = KM * COT / 4, G_F4 = KM * CIT / 4;
+    constexpr int Z_IT = (Z_F4 + 255) / 256, G_IT = (G_F4 + 255) / 256;
+
+    __shared__ __attribute__((aligned(16))) float Zs[KM * LDZ];
+    __shared__ __attribute__((aligned(16))) float Gs[NT][KM * LDG];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int bx = blockIdx.x;
+    const int cot = bx % p.co_tiles; bx /= p.co_tiles;
+    const int cit = bx % p.ci_tiles; bx /= p.ci_tiles;
+    const int tg = bx;
+    const int split = blockIdx.y;
+    const int co0 = cot * COT, ci0 = cit * CIT, t0 = tg * NT;
+    const int Cin = p.Ca + p.Cb, taps = p.ksize * p.ksize;
+    const int HA = p.ups ? (p.Hi >> 1) : p.Hi, WA = p.ups ? (p.Wi >> 1) : p.Wi;
+
+    typedef float accv __attribute__((ext_vector_type(NACC)));
+    accv acc[TPW];
+#pragma unroll
+    for (int s = 0; s < TPW; ++s)
+#pragma unroll
+        for (int r = 0; r < NACC; ++r) acc[s][r] = 0.f;
+
+    const int mbeg = split * p.chunks_per_split * KM;
+    const int mend = min(p.M, mbeg + p.chunks_per_split * KM);
+
+    for (int mc = mbeg; mc < mend; mc += KM) {
+        // ---- global -> registers ------------------------------------------------------------
+        float4 rz[Z_IT], rg[NT][G_IT];
+#pragma unroll
+        for (int it = 0; it < Z_IT; ++it) {
+            const int f = tid + it * 256;
+            const int row = f / (COT / 4), c4 = f % (COT / 4);
+            const int m = mc + row;
+            rz[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (f < Z_F4 && m < mend)
+                rz[it] = *reinterpret_cast<const float4*>(p.dz + (size_t)m * p.Cout + co0 + c4 * 4);
+        }
+#pragma unroll
+        for (int it = 0; it < G_IT; ++it) {
+            const int f = tid + it * 256;
+            const int row = f / (CIT / 4), c4 = f % (CIT / 4);
+            const int m = mc + row;
+            const bool okm = (f < G_F4) && (m < mend);
+            const int mm = okm ? m : 0;
+            const int b = mm / (p.Ho * p.Wo);
+            const int r = mm - b * (p.Ho * p.Wo);
+            const int oy = r / p.Wo, ox = r - oy * p.Wo;
+            const int c = ci0 + c4 * 4;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int tap = t0 + t;
+                const int ky = tap / p.ksize, kx = tap - ky * p.ksize;
+                int iy = oy * p.stride - p.pad + ky, ix = ox * p.stride - p.pad + kx;
+                bool ok = okm && tap < taps;
+                if (p.pad_mode == CLSLAM_PAD_REFLECT) {
+                    iy = reflect_idx(iy, p.Hi);
+                    ix = reflect_idx(ix, p.Wi);
+                } else {
+                    ok = ok && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
+                }
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ok) {
+                    const float* ptr;
+                    if (c < p.Ca) {
+                        const int sy = p.ups ? (iy >> 1) : iy, sx = p.ups ? (ix >> 1) : ix;
+                        ptr = p.src_a + ((size_t)(b * HA + sy) * WA + sx) * p.Ca + c;
+                    } else {
+                        ptr = p.src_b + ((size_t)(b * p.Hi + iy) * p.Wi + ix) * p.Cb + (c - p.Ca);
+                    }
+                    v = *reinterpret_cast<const float4*>(ptr);
+                }
+                rg[t][it] = v;
+            }
+        }
+        __syncthreads();  // previous chunk's MFMAs are done reading LDS
+#pragma unroll
+        for (int it = 0; it < Z_IT; ++it) {
+            const int f = tid + it * 256;
+            if (f < Z_F4) *reinterpret_cast<float4*>(&Zs[(f / (COT / 4)) * LDZ + (f % (COT / 4)) * 4]) = rz[it];
+        }
+#pragma unroll
+        for (int it = 0; it < G_IT; ++it) {
+            const int f = tid + it * 256;
+            if (f < G_F4) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    *reinterpret_cast<float4*>(&Gs[t][(f / (CIT / 4)) * LDG + (f % (CIT / 4)) * 4]) = rg[t][it];
+            }
+        }
+        __syncthreads();
+        // ---- MFMA over the KM pixels of the chunk -------------------------------------------
+#pragma unroll
+        for (int ks = 0; ks < KM / KG; ++ks) {
+            const int row = ks * KG + lane / MF;
+#pragma unroll
+            for (int s = 0; s < TPW; ++s) {
+                const int q = wave + 4 * s;
+                if (q < NTILES) {
+                    const int ti = q % TI, tj = (q / TI) % TJ, t = q / (TI * TJ);
+                    const float a = Zs[row * LDZ + ti * MF + lane % MF];
+                    const float b = Gs[t][row * LDG + tj * MF + lane % MF];
+                    if constexpr (MF == 32) acc[s] = mfma_32x32x2(a, b, acc[s]);
+                    else acc[s] = mfma_16x16x4(a, b, acc[s]);
+                }
+            }
+        }
+    }
+
+    // ---- write this split's partial tile: partial[split][co][tap][ci] -------------------------
+    float* out = p.partial + (size_t)split * p.Cout * taps * Cin;
+#pragma unroll
+    for (int s = 0; s < TPW; ++s) {
+        const int q = wave + 4 * s;
+        if (q >= NTILES) continue;
+        const int ti = q % TI, tj = (q / TI) % TJ, t = q / (TI * TJ);
+        const int tap = t0 + t;
+        if (tap >= taps) continue;
+        const int ci = ci0 + tj * MF + lane % MF;
+#pragma unroll
+        for (int r = 0; r < NACC; ++r) {
+            int row;
+            if constexpr (MF == 32) row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            else row = 4 * (lane >> 4) + r;
+            const int co = co0 + ti * MF + row;
+            out[((size_t)co * taps + tap) * Cin + ci] = acc[s][r];
+        }
+    }
+}
+
+template <int COT, int CIT, int NT, int MF>
+static int launch_wgrad(WgradK k, int splits, hipStream_t stream) {
+    const int taps = k.ksize * k.ksize;
+    k.co_tiles = k.Cout / COT;
+    k.ci_tiles = (k.Ca + k.Cb) / CIT;
+    k.tap_groups = cdiv(taps, NT);
+    hipLaunchKernelGGL((conv_wgrad_kernel<COT, CIT, NT, MF>), dim3(k.co_tiles * k.ci_tiles * k.tap_groups, splits),
+                       dim3(256), 0, stream, k);
+    return check_launch("conv_wgrad");
+}
+
+// out[i] = sum_s partial[s][i]  (fixed order -> deterministic)
+__global__ void reduce_partials_kernel(const float* __restrict__ partial, float* __restrict__ out, size_t n,
+                                       int splits, float scale) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int k = 0; k < splits; ++k) s += partial[(size_t)k * n + i];
+        out[i] = s * scale;
+    }
+}
+
+// partial[blk][c] = sum over the block's rows of x[row][c]
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, float* __restrict__ partial,
+                                                     int M, int C, int rows_per_block) {
+    __shared__ float red[256];
+    const int lanes = 256 / C;  // row lanes (C <= 256)
+    const int c = threadIdx.x % C, rl = threadIdx.x / C;
+    const int r0 = blockIdx.x * rows_per_block;
+    const int r1 = min(M, r0 + rows_per_block);
+    float s = 0.f;
+    if (rl < lanes)
+        for (int r = r0 + rl; r < r1; r += lanes) s += x[(size_t)r * C + c];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x < C) {
+        float t = 0.f;
+        for (int k = 0; k < lanes; ++k) t += red[k * C + threadIdx.x];
+        partial[(size_t)blockIdx.x * C + threadIdx.x] = t;
+    }
+}
+
+}  // namespace clslam
+
+using namespace clslam;
+
+extern "C" int clslam_weight_transpose(const float* w, float* wt, int ch_out, int taps, int ch_in, int ch_in_sel,
+                                       void* stream) {
+    CLSLAM_REQUIRE(w && wt && ch_in_sel <= ch_in, "weight_transpose: bad args");
+    const int total = ch_in_sel * taps * ch_out;
+    if (total == 0) return CLSLAM_OK;
+    hipLaunchKernelGGL(weight_transpose_kernel, dim3(min(1024, cdiv(total, 256))), dim3(256), 0, (hipStream_t)stream,
+                       w, wt, ch_out, taps, ch_in, ch_in_sel);
+    return check_launch("weight_transpose");
+}
+
+extern "C" int clslam_fold_act_grad(const float* dxp, const float* yout, float* dz, int batch, int h, int w, int ch,
+                                    int ch_stride, int border, int pool, int act, void* stream) {
+    CLSLAM_REQUIRE(dxp && dz && ch % 4 == 0 && ch_stride % 4 == 0 && ch <= ch_stride, "fold_act_grad: bad args");
+    CLSLAM_REQUIRE(border == 0 || border == 1, "fold_act_grad: border must be 0/1");
+    CLSLAM_REQUIRE(!pool || (h % 2 == 0 && w % 2 == 0), "fold_act_grad: pooling needs even dims");
+    const size_t total = (size_t)batch * (pool ? h / 2 : h) * (pool ? w / 2 : w) * (ch / 4);
+    if (total == 0) return CLSLAM_OK;
+    const int blocks = (int)std::min<size_t>(4096, (total + 255) / 256);
+    hipLaunchKernelGGL(fold_act_grad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dxp, yout, dz, batch, h, w,
+                       ch, border, pool, act, ch_stride);
+    return check_launch("fold_act_grad");
+}
+
+static void pick_wgrad_tile(const clslam_conv_desc* d, int* cot, int* nt) {
+    const int Cin = d->ch_a + d->ch_b, taps = d->ksize * d->ksize;
+    const bool c64 = d->ch_out % 64 == 0 && Cin % 64 == 0 && (d->ch_b == 0 || d->ch_a % 64 == 0);
+    const bool c32 = d->ch_out % 32 == 0 && Cin % 32 == 0 && (d->ch_b == 0 || d->ch_a % 32 == 0);
+    if (c64) { *cot = 64; *nt = taps == 9 ? 3 : 1; }
+    else if (c32) { *cot = 32; *nt = taps == 9 ? 9 : 1; }
+    else { *cot = 16; *nt = taps == 9 ? 9 : 1; }
+}
+
+// Number of pixel-range splits clslam_conv_wgrad should be launched with so that the grid has
+// about target_blocks workgroups (the caller sizes the partial buffer from it).
+extern "C" int clslam_wgrad_splits(const clslam_conv_desc* d, int target_blocks) {
+    const int M = d->batch * d->out_h * d->out_w;
+    const int Cin = d->ch_a + d->ch_b, taps = d->ksize * d->ksize;
+    int T, NT;
+    pick_wgrad_tile(d, &T, &NT);
+    const int tiles = (d->ch_out / T) * (Cin / T) * cdiv(taps, NT);
+    const int chunks = std::max(1, cdiv(M, 32));
+    const int splits = std::max(1, std::min(chunks, cdiv(target_blocks, tiles)));
+    const int cps = cdiv(chunks, splits);
+    return cdiv(chunks, cps);
+}
+
+// dW partials.  desc describes the FORWARD conv (src_a/src_b/geometry); dz = d(pre-activation
+// output) [B*out_h*out_w][ch_out]; partial holds splits*ch_out*taps*(ch_a+ch_b) floats.
+extern "C" int clslam_conv_wgrad(const clslam_conv_desc* d, const float* dz, float* partial, int splits, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    CLSLAM_REQUIRE(d && dz && partial && d->src_a && splits >= 1, "conv_wgrad: bad args");
+    const int Cin = d->ch_a + d->ch_b, taps = d->ksize * d->ksize;
+    CLSLAM_REQUIRE(taps == 1 || taps == 9, "conv_wgrad: ksize must be 1 or 3");
+    CLSLAM_REQUIRE(d->ch_out % 16 == 0 && Cin % 16 == 0 && d->ch_a % 16 == 0, "conv_wgrad: channels must be multiples of 16");
+    WgradK k;
+    k.dz = dz; k.src_a = d->src_a; k.src_b = d->src_b; k.partial = partial;
+    k.B = d->batch; k.Hi = d->in_h; k.Wi = d->in_w; k.Ca = d->ch_a; k.Cb = d->ch_b; k.Ho = d->out_h; k.Wo = d->out_w;
+    k.Cout = d->ch_out; k.ksize = d->ksize; k.stride = d->stride; k.pad = d->pad; k.pad_mode = d->pad_mode;
+    k.ups = d->upsample_a;
+    k.M = d->batch * d->out_h * d->out_w;
+    const int chunks = std::max(1, cdiv(k.M, 32));
+    k.chunks_per_split = cdiv(chunks, splits);
+    k.co_tiles = k.ci_tiles = k.tap_groups = 0;
+    int T, NT;
+    pick_wgrad_tile(d, &T, &NT);
+    if (T == 64) return NT == 3 ? launch_wgrad<64, 64, 3, 32>(k, splits, stream) : launch_wgrad<64, 64, 1, 32>(k, splits, stream);
+    if (T == 32) return NT == 9 ? launch_wgrad<32, 32, 9, 32>(k, splits, stream) : launch_wgrad<32, 32, 1, 32>(k, splits, stream);
+    return NT == 9 ? launch_wgrad<16, 16, 9, 16>(k, splits, stream) : launch_wgrad<16, 16, 1, 16>(k, splits, stream);
+}
+
+extern "C" int clslam_reduce_partials(const float* partial, float* out, size_t n, int splits, float scale, void* stream) {
+    CLSLAM_REQUIRE(partial && out, "reduce_partials: null");
+    if (n == 0) return CLSLAM_OK;
+    const int blocks = (int)std::min<size_t>(2048, (n + 255) / 256);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, partial, out, n, splits, scale);
+    return check_launch("reduce_partials");
+}
+
+extern "C" int clslam_colsum_blocks(int rows) { return std::max(1, std::min(1024, cdiv(rows, 256))); }
+
+// partial must hold clslam_colsum_blocks(rows)*ch floats; follow with clslam_reduce_partials.
+extern "C" int clslam_colsum(const float* x, float* partial, int rows, int ch, void* stream) {
+    CLSLAM_REQUIRE(x && partial && ch >= 1 && ch <= 256, "colsum: ch must be in [1,256]");
+    const int blocks = clslam_colsum_blocks(rows);
+    const int rpb = cdiv(std::max(rows, 1), blocks);
+    hipLaunchKernelGGL(colsum_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, partial, rows, ch, rpb);
+    return check_launch("colsum");
+}

@@ -30,7 +30,9 @@ struct ConvK {
     const float* __restrict__ scale;
     const float* __restrict__ shift;
     const float* __restrict__ residual;
+    const float* __restrict__ actgrad_src;
     float* __restrict__ out;
+    int actgrad_kind;
     int B, Hi, Wi, Ca, Cb, Ho, Wo, Cout;
     int ksize, stride, pad, pad_mode, ups, act;
     int M, tilesM, tilesN, nblk;
@@ -206,7 +208,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvK p) {
                 if (m >= p.M) continue;
                 float v = acc[i][j][r] * sc + sh;
                 if (p.residual) v += p.residual[(size_t)m * p.Cout + n];
-                p.out[(size_t)m * p.Cout + n] = apply_act(v, p.act);
+                v = apply_act(v, p.act);
+                if (p.actgrad_src) v *= act_grad_from_output(p.actgrad_src[(size_t)m * p.Cout + n], p.actgrad_kind);
+                p.out[(size_t)m * p.Cout + n] = v;
             }
         }
     }
@@ -246,7 +250,7 @@ extern "C" int clslam_conv2d(const clslam_conv_desc* d, void* stream_) {
     CLSLAM_REQUIRE(d->ch_b == 0 || d->src_b, "conv2d: src_b missing");
     ConvK k;
     k.src_a = d->src_a; k.src_b = d->src_b; k.wgt = d->weight; k.scale = d->scale; k.shift = d->shift;
-    k.residual = d->residual; k.out = d->out;
+    k.residual = d->residual; k.out = d->out; k.actgrad_src = d->actgrad_src; k.actgrad_kind = d->actgrad_kind;
     k.B = d->batch; k.Hi = d->in_h; k.Wi = d->in_w; k.Ca = d->ch_a; k.Cb = d->ch_b;
     k.Ho = d->out_h; k.Wo = d->out_w; k.Cout = d->ch_out;
     k.ksize = d->ksize; k.stride = d->stride; k.pad = d->pad; k.pad_mode = d->pad_mode;

@@ -64,8 +64,37 @@ typedef struct clslam_conv_desc {
     int32_t batch, in_h, in_w, ch_a, ch_b, out_h, out_w, ch_out;
     int32_t ksize, stride, pad, pad_mode, upsample_a, act;
     int32_t config;        /* tile configuration, -1 = choose                                  */
+    /* dgrad epilogue: out *= act'(y) where y = actgrad_src[b,oy,ox,n] is the OUTPUT of the
+     * activation being differentiated (ReLU' = y>0, ELU' = y>0 ? 1 : y+1). NULL = off.        */
+    const float* actgrad_src;
+    int32_t actgrad_kind;
 } clslam_conv_desc;
 int clslam_conv2d(const clslam_conv_desc* desc, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Backward of the trainable convolutions -- replaces autograd's convolution_backward,
+ * reflection_pad2d_backward, upsample_nearest2d_backward, cat backward, elu/relu backward for
+ * networks/depth_decoder.py:51-71, networks/layers.py:9-48, networks/pose_decoder.py:37-54
+ * (entered from dpp.py:312 `losses['loss'].backward()`).                                      */
+
+/* wt[ci][taps-1-t][co] = w[co][t][ci] for ci < ch_in_sel: the weights of the dgrad-as-conv.    */
+int clslam_weight_transpose(const float* w, float* wt, int ch_out, int taps, int ch_in, int ch_in_sel,
+                            void* stream);
+/* dz = act'(yout) * fold(dxp): dxp is the gradient w.r.t. the PADDED conv input
+ * [B][h+2*border][w+2*border][ch_stride]; border=1 folds the reflection border back
+ * (ReflectionPad2d backward), pool=1 sums each 2x2 block (nearest-2x upsample backward, output
+ * is [B][h/2][w/2][ch]); only channels [0,ch) are used (the skip half of a concat is dead:
+ * encoders are frozen, dpp.py:308,813-819); yout may be NULL (no activation).                 */
+int clslam_fold_act_grad(const float* dxp, const float* yout, float* dz, int batch, int h, int w, int ch,
+                         int ch_stride, int border, int pool, int act, void* stream);
+/* Weight gradient as an MFMA GEMM reducing over pixels; desc = the forward conv's descriptor. */
+int clslam_wgrad_splits(const clslam_conv_desc* desc, int target_blocks);
+int clslam_conv_wgrad(const clslam_conv_desc* desc, const float* dz, float* partial, int splits, void* stream);
+/* out[i] = scale * sum_s partial[s*n + i] in a fixed order (deterministic).                    */
+int clslam_reduce_partials(const float* partial, float* out, size_t n, int splits, float scale, void* stream);
+/* bias gradient: column sums of x[rows][ch], stage 1 (follow with clslam_reduce_partials).     */
+int clslam_colsum_blocks(int rows);
+int clslam_colsum(const float* x, float* partial, int rows, int ch, void* stream);
 
 #ifdef __cplusplus
 }

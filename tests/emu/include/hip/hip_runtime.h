@@ -61,6 +61,8 @@ inline void hipLaunchKernelGGL(void (*kernel)(KArgs...), dim3 grid, dim3 block, 
     emu_launch([=]() { kernel(static_cast<KArgs>(args)...); }, grid, block);
 }
 
+using std::min;
+using std::max;
 inline float __expf(float x) { return expf(x); }
 inline float __fdividef(float a, float b) { return a / b; }
 inline float atomicAdd(float* p, float v) {

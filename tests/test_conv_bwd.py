@@ -1,0 +1,93 @@
+"""Backward conv pieces (dgrad = transpose + conv2d + fold, wgrad, bias colsum) vs torch autograd."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from clslam_hip import ops
+from emu_util import BACKENDS, use_backend
+from helpers import rel_err
+
+# B, H(out res), W, Ca, Cb, Cout, k, reflect, ups, act
+CASES = [
+    (2, 8, 12, 32, 0, 16, 3, True, False, 2),     # upconv_0_0-like
+    (1, 8, 16, 16, 0, 16, 3, True, True, 2),      # upconv_0_1-like (upsampled input)
+    (1, 8, 8, 32, 64, 32, 3, True, True, 2),      # upconv_1_1-like (upsample + skip concat)
+    (2, 4, 6, 64, 64, 64, 3, True, True, 2),      # upconv_2_1-like, 64-tiles
+    (2, 6, 10, 64, 0, 64, 3, False, False, 1),    # pose_0-like (zero pad, relu)
+    (2, 6, 10, 64, 0, 64, 1, False, False, 1),    # squeeze-like 1x1
+]
+
+
+def _forward(xa, xb, w_ohwi, bias, k, reflect, ups, act):
+    x = xa.permute(0, 3, 1, 2)
+    if ups:
+        x = F.interpolate(x, scale_factor=2, mode='nearest')
+    if xb is not None:
+        x = torch.cat([x, xb.permute(0, 3, 1, 2)], 1)
+    Cout = w_ohwi.shape[0]
+    w = w_ohwi.reshape(Cout, k, k, -1).permute(0, 3, 1, 2)
+    pad = k // 2
+    if pad:
+        x = F.pad(x, (pad,) * 4, mode='reflect' if reflect else 'constant')
+    z = F.conv2d(x, w, bias)
+    y = F.relu(z) if act == 1 else F.elu(z)
+    return z, y
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+@pytest.mark.parametrize('case', CASES)
+def test_conv_backward_matches_autograd(case, backend):
+    B, H, W, Ca, Cb, Cout, k, reflect, ups, act = case
+    dev = use_backend(backend)
+    g = torch.Generator().manual_seed(1234 + hash(case) % 1000)
+    Ha, Wa = (H // 2, W // 2) if ups else (H, W)
+    # xa is itself the output of an activation (so that dxa gets multiplied by act'(xa))
+    xa_pre = torch.randn(B, Ha, Wa, Ca, generator=g)
+    xa_pre.requires_grad_(True)
+    xa = F.elu(xa_pre) if act == 2 else F.relu(xa_pre)
+    xb = torch.randn(B, H, W, Cb, generator=g) if Cb else None
+    w = (torch.randn(Cout, k * k, Ca + Cb, generator=g) / (k * (Ca + Cb) ** 0.5)).requires_grad_(True)
+    bias = (torch.randn(Cout, generator=g) * 0.1).requires_grad_(True)
+    z, y = _forward(xa, xb, w, bias, k, reflect, ups, act)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    # dz = dy * act'(y)  (NHWC)
+    with torch.no_grad():
+        yn = y.permute(0, 2, 3, 1).contiguous()
+        dyn = dy.permute(0, 2, 3, 1).contiguous()
+        actg = (yn > 0).float() if act == 1 else torch.where(yn > 0, torch.ones_like(yn), yn + 1)
+        dz = (dyn * actg).contiguous()
+    t = lambda v: None if v is None else v.detach().contiguous().to(dev)
+    dz_d, xa_d, xb_d, w_d = t(dz), t(xa), t(xb), t(w)
+
+    # ---- wgrad -------------------------------------------------------------------------------
+    desc = ops.conv_desc(xa_d, (B, H, W, Cout), src_b=xb_d, ksize=k, pad_mode=1 if reflect else 0, upsample_a=ups)
+    for target in (1, 64):
+        splits = ops.wgrad_splits(desc, target)
+        n = w.numel()
+        partial = torch.full((splits * n,), float('nan'), device=dev)
+        ops.conv_wgrad(desc, dz_d, partial, splits)
+        dw = torch.empty(n, device=dev)
+        ops.reduce_partials(partial, dw, n, splits)
+        assert rel_err(dw.cpu().view_as(w), w.grad) < 2e-5, (target, splits)
+    # ---- bias grad ---------------------------------------------------------------------------
+    rows = B * H * W
+    nb = ops.colsum_blocks(rows)
+    part = torch.empty(nb * Cout, device=dev)
+    ops.colsum(dz_d, part, rows, Cout)
+    db = torch.empty(Cout, device=dev)
+    ops.reduce_partials(part, db, Cout, nb)
+    assert rel_err(db.cpu(), bias.grad) < 2e-5
+    # ---- dgrad w.r.t. the pre-activation of xa -----------------------------------------------
+    taps = k * k
+    wt = torch.empty(Ca * taps * Cout, device=dev)
+    ops.weight_transpose(w_d, wt.view(Ca, taps, Cout), ch_in_sel=Ca)
+    if k == 3 and reflect:
+        dxp = torch.full((B, H + 2, W + 2, Ca), float('nan'), device=dev)
+        ops.conv2d(dz_d, wt.view(Ca, taps, Cout), dxp, ksize=3, pad=2)
+        dpre = torch.empty(B, Ha, Wa, Ca, device=dev)
+        ops.fold_act_grad(dxp, xa_d, dpre, h=H, w=W, ch=Ca, border=1, pool=ups, act=act)
+    else:
+        dpre = torch.full((B, H, W, Ca), float('nan'), device=dev)
+        ops.conv2d(dz_d, wt.view(Ca, taps, Cout), dpre, ksize=k, pad=k // 2, actgrad_src=xa_d, actgrad_kind=act)
+    assert rel_err(dpre.cpu(), xa_pre.grad) < 2e-5
