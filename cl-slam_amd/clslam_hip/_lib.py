@@ -40,6 +40,14 @@ _SIGNATURES = {
     'clslam_reduce_partials': [fptr, fptr, C.c_size_t, i32, C.c_float, C.c_void_p],
     'clslam_colsum_blocks': [i32],
     'clslam_colsum': [fptr, fptr, i32, i32, C.c_void_p],
+    'clslam_stem_conv': [fptr, fptr, fptr, fptr, fptr, fptr, i32, i32, i32, i32, C.c_void_p],
+    'clslam_maxpool3x3s2': [fptr, fptr, i32, i32, i32, i32, C.c_void_p],
+    'clslam_dispconv_fwd': [fptr, fptr, fptr, fptr, i32, i32, i32, i32, C.c_void_p],
+    'clslam_dispconv_bwd_data': [fptr, fptr, fptr, i32, i32, i32, i32, i32, C.c_void_p],
+    'clslam_dispconv_wgrad_blocks': [i32],
+    'clslam_dispconv_wgrad': [fptr, fptr, fptr, i32, i32, i32, i32, C.c_void_p],
+    'clslam_pose_head_fwd': [fptr, fptr, fptr, fptr, fptr, i32, i32, C.c_void_p],
+    'clslam_pose_head_bwd': [fptr, fptr, fptr, fptr, fptr, fptr, fptr, i32, i32, C.c_float, C.c_void_p],
 }
 _RESTYPES = {'clslam_last_error': C.c_char_p}
 

@@ -92,3 +92,52 @@ def colsum_blocks(rows: int) -> int:
 def colsum(x, partial, rows, ch):
     _lib.get_lib().call('clslam_colsum', _p(x), _p(partial), rows, ch, _stream(x))
     return partial
+
+
+def stem_conv(img_a, img_b, weight, scale, shift, out):
+    """img_* planar (B,3,H,W); weight OIHW (64,3|6,7,7); out NHWC (B,H/2,W/2,64)."""
+    B, _, H, W = img_a.shape
+    n_img = 1 if img_b is None else 2
+    _lib.get_lib().call('clslam_stem_conv', _p(img_a), _p(img_b), _p(weight), _p(scale), _p(shift), _p(out),
+                        B, H, W, n_img, _stream(out))
+    return out
+
+
+def maxpool3x3s2(x, out):
+    B, H, W, Cc = x.shape
+    _lib.get_lib().call('clslam_maxpool3x3s2', _p(x), _p(out), B, H, W, Cc, _stream(out))
+    return out
+
+
+def dispconv_fwd(x, w, bias, disp):
+    B, H, W, Cc = x.shape
+    _lib.get_lib().call('clslam_dispconv_fwd', _p(x), _p(w), _p(bias), _p(disp), B, H, W, Cc, _stream(disp))
+    return disp
+
+
+def dispconv_bwd_data(dz, w, dxp, ch, accumulate):
+    B, H, W = dz.shape[0], dz.shape[-2], dz.shape[-1]
+    _lib.get_lib().call('clslam_dispconv_bwd_data', _p(dz), _p(w), _p(dxp), B, H, W, ch, int(accumulate), _stream(dxp))
+    return dxp
+
+
+def dispconv_wgrad_blocks(pixels: int) -> int:
+    return _lib.get_lib().cdll.clslam_dispconv_wgrad_blocks(pixels)
+
+
+def dispconv_wgrad(dz, x, partial):
+    B, H, W, Cc = x.shape
+    _lib.get_lib().call('clslam_dispconv_wgrad', _p(dz), _p(x), _p(partial), B, H, W, Cc, _stream(x))
+    return partial
+
+
+def pose_head_fwd(x, w2, b2, mean, pose):
+    N, H, W, _ = x.shape
+    _lib.get_lib().call('clslam_pose_head_fwd', _p(x), _p(w2), _p(b2), _p(mean), _p(pose), N, H * W, _stream(x))
+    return pose
+
+
+def pose_head_bwd(dpose, x, w2, mean, dz1, dw2, db2, grad_scale=1.0):
+    N, H, W, _ = x.shape
+    _lib.get_lib().call('clslam_pose_head_bwd', _p(dpose), _p(x), _p(w2), _p(mean), _p(dz1), _p(dw2), _p(db2),
+                        N, H * W, grad_scale, _stream(x))

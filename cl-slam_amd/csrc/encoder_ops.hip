@@ -1,0 +1,136 @@
+// K1/K2: ResNet stem for the frozen depth / pose encoders.
+//   stem   : (x - 0.45)/0.225 (reference networks/resnet_encoder.py:117) -> conv7x7 s2 p3, no bias
+//            (:118, torchvision ResNet.conv1 / ResNetMultiImageInput :25-30) -> eval BatchNorm
+//            (scale/shift) -> ReLU (:119-120), reading the PLANAR NCHW images of the reference's
+//            sample dict directly (for the pose net the two frames are two pointers, the
+//            torch.cat of dpp.py:951-955 never materialises) and writing NHWC.
+//   maxpool: 3x3 s2 p1 (:121).
+// The stem is an implicit GEMM on v_mfma_f32_32x32x2_f32: M = 8x16 output pixels per block,
+// N = 64 output channels, K = 49 taps (+1 zero) per input channel; per channel the 21x37 input
+// patch (normalised, zero outside the image = zero padding of the normalised tensor) and the
+// 64x49 weight slice are staged in LDS.
+#include "common.h"
+
+namespace clslam {
+
+constexpr int ST_TH = 8, ST_TW = 16;                  // output tile
+constexpr int ST_PH = 2 * ST_TH + 5, ST_PW = 2 * ST_TW + 5;  // 21 x 37 input patch
+constexpr int ST_LDW = 51;                            // weight row stride (odd -> conflict-free column reads)
+
+__global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict__ img_a, const float* __restrict__ img_b,
+                                                        const float* __restrict__ w, const float* __restrict__ scale,
+                                                        const float* __restrict__ shift, float* __restrict__ out,
+                                                        int B, int H, int W, int Cin, int Ho, int Wo, int tiles_x,
+                                                        int tiles_y) {
+    __shared__ float patch[ST_PH * ST_PW];
+    __shared__ float Ws[64 * ST_LDW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int bid = blockIdx.x;
+    const int tx = bid % tiles_x; bid /= tiles_x;
+    const int ty = bid % tiles_y; bid /= tiles_y;
+    const int b = bid;
+    const int oy0 = ty * ST_TH, ox0 = tx * ST_TW;
+    const int iy0 = 2 * oy0 - 3, ix0 = 2 * ox0 - 3;
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    const int i = lane & 31, g = lane >> 5;
+    const int py = wave * 2 + (i >> 4), px = i & 15;      // this lane's output pixel inside the tile
+    const int pbase = (2 * py) * ST_PW + 2 * px;
+
+    for (int c = 0; c < Cin; ++c) {
+        const float* img = (c < 3) ? img_a + ((size_t)b * 3 + c) * H * W : img_b + ((size_t)b * 3 + (c - 3)) * H * W;
+        __syncthreads();
+        for (int e = tid; e < ST_PH * ST_PW; e += 256) {
+            const int r = e / ST_PW, q = e - r * ST_PW;
+            const int iy = iy0 + r, ix = ix0 + q;
+            float v = 0.f;
+            if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = (img[(size_t)iy * W + ix] - 0.45f) / 0.225f;
+            patch[e] = v;
+        }
+        for (int e = tid; e < 64 * 50; e += 256) {
+            const int co = e / 50, k = e - co * 50;
+            Ws[co * ST_LDW + k] = (k < 49) ? w[((size_t)co * Cin + c) * 49 + k] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll 5
+        for (int s = 0; s < 25; ++s) {
+            const int k = 2 * s + g;
+            const int kk = k < 49 ? k : 0;                 // k = 49 is the zero pad column
+            const int ky = kk / 7, kx = kk - ky * 7;
+            const float a = patch[pbase + ky * ST_PW + kx];
+            const float b0 = Ws[i * ST_LDW + k];
+            const float b1 = Ws[(32 + i) * ST_LDW + k];
+            acc[0] = mfma_32x32x2(a, b0, acc[0]);
+            acc[1] = mfma_32x32x2(a, b1, acc[1]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = j * 32 + i;
+        const float sc = scale[n], sh = shift[n];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * g;  // pixel index inside the wave's 32
+            const int oy = oy0 + wave * 2 + (row >> 4), ox = ox0 + (row & 15);
+            if (oy < Ho && ox < Wo) {
+                const float v = acc[j][r] * sc + sh;
+                out[(((size_t)b * Ho + oy) * Wo + ox) * 64 + n] = v > 0.f ? v : 0.f;
+            }
+        }
+    }
+}
+
+__global__ void maxpool3x3s2_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int H, int W, int C,
+                                    int Ho, int Wo) {
+    const int C4 = C / 4;
+    const size_t total = (size_t)B * Ho * Wo * C4;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(idx % C4);
+        const int ox = (int)((idx / C4) % Wo);
+        const int oy = (int)((idx / ((size_t)C4 * Wo)) % Ho);
+        const int b = (int)(idx / ((size_t)C4 * Wo * Ho));
+        float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = 2 * oy - 1 + ky;
+            if (iy < 0 || iy >= H) continue;
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = 2 * ox - 1 + kx;
+                if (ix < 0 || ix >= W) continue;
+                const float4 v = *reinterpret_cast<const float4*>(in + (((size_t)b * H + iy) * W + ix) * C + c4 * 4);
+                m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+            }
+        }
+        *reinterpret_cast<float4*>(out + (((size_t)b * Ho + oy) * Wo + ox) * C + c4 * 4) = m;
+    }
+}
+
+}  // namespace clslam
+
+using namespace clslam;
+
+extern "C" int clslam_stem_conv(const float* img_a, const float* img_b, const float* weight, const float* scale,
+                                const float* shift, float* out, int batch, int h, int w, int num_images, void* stream) {
+    CLSLAM_REQUIRE(img_a && weight && scale && shift && out, "stem_conv: null pointer");
+    CLSLAM_REQUIRE(num_images == 1 || (num_images == 2 && img_b), "stem_conv: num_images must be 1 or 2");
+    const int Ho = (h + 6 - 7) / 2 + 1, Wo = (w + 6 - 7) / 2 + 1;
+    const int tx = cdiv(Wo, ST_TW), ty = cdiv(Ho, ST_TH);
+    if (batch == 0) return CLSLAM_OK;
+    hipLaunchKernelGGL(stem_conv_kernel, dim3(tx * ty * batch), dim3(256), 0, (hipStream_t)stream, img_a, img_b, weight,
+                       scale, shift, out, batch, h, w, 3 * num_images, Ho, Wo, tx, ty);
+    return check_launch("stem_conv");
+}
+
+extern "C" int clslam_maxpool3x3s2(const float* in, float* out, int batch, int h, int w, int ch, void* stream) {
+    CLSLAM_REQUIRE(in && out && ch % 4 == 0, "maxpool: bad args");
+    const int Ho = (h + 2 - 3) / 2 + 1, Wo = (w + 2 - 3) / 2 + 1;
+    const size_t total = (size_t)batch * Ho * Wo * (ch / 4);
+    if (total == 0) return CLSLAM_OK;
+    hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3((unsigned)std::min<size_t>(4096, (total + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, in, out, batch, h, w, ch, Ho, Wo);
+    return check_launch("maxpool3x3s2");
+}

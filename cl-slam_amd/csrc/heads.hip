@@ -1,0 +1,238 @@
+// K6/K16 and K7-tail/K17-head: the two thin output heads.
+//   dispconv : reflection-padded 3x3 conv C -> 1 + sigmoid (reference networks/depth_decoder.py:67-69,
+//              layers.py:28-48) -- a 9*C dot product per pixel, HBM-bound, no MFMA (N = 1).
+//   pose head: pose_2 1x1 conv 256 -> 12, spatial mean, x0.01 (reference networks/pose_decoder.py:44-54).
+//              mean and the 1x1 conv commute (both linear), so the head is mean -> 12x256 matvec.
+// plus their backward passes (autograd of the same lines).
+#include "common.h"
+
+namespace clslam {
+
+// ------------------------------------------------------------------------------------------------
+// disp[b,y,x] = sigmoid(bias + sum_{tap,c} x[b, refl(y+ky-1), refl(x+kx-1), c] * w[tap][c])
+__global__ __launch_bounds__(256) void dispconv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, float* __restrict__ disp,
+                                                           int B, int H, int W, int C) {
+    __shared__ __attribute__((aligned(16))) float ws[9 * 256];
+    for (int e = threadIdx.x; e < 9 * C; e += 256) ws[e] = w[e];
+    __syncthreads();
+    const size_t total = (size_t)B * H * W;
+    const float bv = bias[0];
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int xx = (int)(idx % W);
+        const int yy = (int)((idx / W) % H);
+        const int b = (int)(idx / ((size_t)W * H));
+        float acc = 0.f;
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = reflect_idx(yy + ky - 1, H);
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = reflect_idx(xx + kx - 1, W);
+                const float* px = x + (((size_t)b * H + iy) * W + ix) * C;
+                const float* pw = ws + (ky * 3 + kx) * C;
+                for (int c = 0; c < C; c += 4) {
+                    const float4 v = *reinterpret_cast<const float4*>(px + c);
+                    const float4 k = *reinterpret_cast<const float4*>(pw + c);
+                    acc = fmaf(v.x, k.x, acc); acc = fmaf(v.y, k.y, acc);
+                    acc = fmaf(v.z, k.z, acc); acc = fmaf(v.w, k.w, acc);
+                }
+            }
+        }
+        acc += bv;
+        disp[idx] = 1.f / (1.f + expf(-acc));
+    }
+}
+
+// dxp[b,Py,Px,c] (+)= sum_{ky,kx} dz[b,Py-2+ky,Px-2+kx] * w[(2-ky)*3+(2-kx)][c]   (padded domain)
+__global__ __launch_bounds__(256) void dispconv_bwd_data_kernel(const float* __restrict__ dz, const float* __restrict__ w,
+                                                                float* __restrict__ dxp, int B, int H, int W, int C,
+                                                                int accumulate) {
+    __shared__ __attribute__((aligned(16))) float ws[9 * 256];
+    for (int e = threadIdx.x; e < 9 * C; e += 256) ws[e] = w[e];
+    __syncthreads();
+    const int C4 = C / 4, Hp = H + 2, Wp = W + 2;
+    const size_t total = (size_t)B * Hp * Wp * C4;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(idx % C4);
+        const int Px = (int)((idx / C4) % Wp);
+        const int Py = (int)((idx / ((size_t)C4 * Wp)) % Hp);
+        const int b = (int)(idx / ((size_t)C4 * Wp * Hp));
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int ky = 0; ky < 3; ++ky) {
+            const int yy = Py - 2 + ky;
+            if (yy < 0 || yy >= H) continue;
+            for (int kx = 0; kx < 3; ++kx) {
+                const int xx = Px - 2 + kx;
+                if (xx < 0 || xx >= W) continue;
+                const float g = dz[((size_t)b * H + yy) * W + xx];
+                const float4 k = *reinterpret_cast<const float4*>(ws + ((2 - ky) * 3 + (2 - kx)) * C + c4 * 4);
+                acc.x = fmaf(g, k.x, acc.x); acc.y = fmaf(g, k.y, acc.y);
+                acc.z = fmaf(g, k.z, acc.z); acc.w = fmaf(g, k.w, acc.w);
+            }
+        }
+        float4* o = reinterpret_cast<float4*>(dxp + (((size_t)b * Hp + Py) * Wp + Px) * C + c4 * 4);
+        if (accumulate) {
+            const float4 p = *o;
+            acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w;
+        }
+        *o = acc;
+    }
+}
+
+// partial[blk][tap][c] = sum over the block's pixels of dz * x(tap shifted); partial[blk][9*C] = sum dz
+__global__ __launch_bounds__(256) void dispconv_wgrad_kernel(const float* __restrict__ dz, const float* __restrict__ x,
+                                                             float* __restrict__ partial, int B, int H, int W, int C,
+                                                             int pix_per_block) {
+    __shared__ float red[37 * 256];
+    const int C4 = C / 4;
+    const int lanes = 256 / C4;                // pixel lanes (C4 <= 64)
+    const int cq = threadIdx.x % C4, pl = threadIdx.x / C4;
+    const int total = B * H * W;
+    const int p0 = blockIdx.x * pix_per_block, p1 = min(total, p0 + pix_per_block);
+    float acc[36];
+#pragma unroll
+    for (int k = 0; k < 36; ++k) acc[k] = 0.f;
+    float bsum = 0.f;
+    if (pl < lanes) {
+        for (int p = p0 + pl; p < p1; p += lanes) {
+            const int xx = p % W, yy = (p / W) % H, b = p / (W * H);
+            const float g = dz[p];
+            if (cq == 0) bsum += g;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int iy = reflect_idx(yy + ky - 1, H);
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int ix = reflect_idx(xx + kx - 1, W);
+                    const float4 v = *reinterpret_cast<const float4*>(x + (((size_t)b * H + iy) * W + ix) * C + cq * 4);
+                    const int t = (ky * 3 + kx) * 4;
+                    acc[t + 0] = fmaf(g, v.x, acc[t + 0]); acc[t + 1] = fmaf(g, v.y, acc[t + 1]);
+                    acc[t + 2] = fmaf(g, v.z, acc[t + 2]); acc[t + 3] = fmaf(g, v.w, acc[t + 3]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 36; ++k) red[k * 256 + threadIdx.x] = acc[k];
+    red[36 * 256 + threadIdx.x] = bsum;
+    __syncthreads();
+    float* out = partial + (size_t)blockIdx.x * (9 * C + 1);
+    for (int e = threadIdx.x; e < 9 * C; e += 256) {
+        const int tap = e / C, c = e - tap * C;
+        const int q = c >> 2, comp = c & 3;
+        float s = 0.f;
+        for (int l = 0; l < lanes; ++l) s += red[(tap * 4 + comp) * 256 + l * C4 + q];
+        out[e] = s;
+    }
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+        for (int l = 0; l < lanes; ++l) s += red[36 * 256 + l * C4];
+        out[9 * C] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// One block per pose pass n: mean over pixels of x[n,:, :256], then the 12x256 matvec, x0.01.
+__global__ __launch_bounds__(256) void pose_head_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w2,
+                                                            const float* __restrict__ b2, float* __restrict__ mean,
+                                                            float* __restrict__ pose, int HW) {
+    __shared__ float ms[256];
+    const int n = blockIdx.x, c = threadIdx.x;
+    float s = 0.f;
+    for (int p = 0; p < HW; ++p) s += x[((size_t)n * HW + p) * 256 + c];
+    s = s / (float)HW;
+    ms[c] = s;
+    mean[(size_t)n * 256 + c] = s;
+    __syncthreads();
+    if (c < 12) {
+        float a = 0.f;
+        for (int k = 0; k < 256; ++k) a = fmaf(w2[c * 256 + k], ms[k], a);
+        pose[n * 12 + c] = 0.01f * (a + b2[c]);
+    }
+}
+
+// blocks [0,N): dz1[n,p,c] = relu'(x) * (sum_o w2[o][c] * 0.01*dpose[n][o]) / HW
+// block N     : dw2[o][c] = sum_n 0.01*dpose[n][o]*mean[n][c], db2[o] = sum_n 0.01*dpose[n][o]
+__global__ __launch_bounds__(256) void pose_head_bwd_kernel(const float* __restrict__ dpose, const float* __restrict__ x,
+                                                            const float* __restrict__ w2, const float* __restrict__ mean,
+                                                            float* __restrict__ dz1, float* __restrict__ dw2,
+                                                            float* __restrict__ db2, int N, int HW, float gscale) {
+    const int c = threadIdx.x;
+    if ((int)blockIdx.x == N) {
+        for (int o = 0; o < 12; ++o) {
+            float s = 0.f;
+            for (int n = 0; n < N; ++n) s = fmaf(0.01f * dpose[n * 12 + o], mean[(size_t)n * 256 + c], s);
+            dw2[o * 256 + c] = s * gscale;
+        }
+        if (c < 12) {
+            float s = 0.f;
+            for (int n = 0; n < N; ++n) s += 0.01f * dpose[n * 12 + c];
+            db2[c] = s * gscale;
+        }
+        return;
+    }
+    const int n = blockIdx.x;
+    float dm = 0.f;
+    for (int o = 0; o < 12; ++o) dm = fmaf(w2[o * 256 + c], 0.01f * dpose[n * 12 + o], dm);
+    dm = dm / (float)HW;
+    for (int p = 0; p < HW; ++p) {
+        const size_t i = ((size_t)n * HW + p) * 256 + c;
+        dz1[i] = x[i] > 0.f ? dm : 0.f;
+    }
+}
+
+}  // namespace clslam
+
+using namespace clslam;
+
+static int grid_for(size_t total) { return (int)std::min<size_t>(4096, (total + 255) / 256); }
+
+extern "C" int clslam_dispconv_fwd(const float* x, const float* w, const float* bias, float* disp, int batch, int h,
+                                   int wd, int ch, void* stream) {
+    CLSLAM_REQUIRE(x && w && bias && disp && ch % 4 == 0 && ch <= 256, "dispconv_fwd: bad args");
+    const size_t total = (size_t)batch * h * wd;
+    if (!total) return CLSLAM_OK;
+    hipLaunchKernelGGL(dispconv_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, w, bias, disp,
+                       batch, h, wd, ch);
+    return check_launch("dispconv_fwd");
+}
+
+extern "C" int clslam_dispconv_bwd_data(const float* dz, const float* w, float* dxp, int batch, int h, int wd, int ch,
+                                        int accumulate, void* stream) {
+    CLSLAM_REQUIRE(dz && w && dxp && ch % 4 == 0 && ch <= 256, "dispconv_bwd_data: bad args");
+    const size_t total = (size_t)batch * (h + 2) * (wd + 2) * (ch / 4);
+    if (!total) return CLSLAM_OK;
+    hipLaunchKernelGGL(dispconv_bwd_data_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dz, w, dxp,
+                       batch, h, wd, ch, accumulate);
+    return check_launch("dispconv_bwd_data");
+}
+
+extern "C" int clslam_dispconv_wgrad_blocks(int pixels) { return std::max(1, std::min(512, cdiv(pixels, 512))); }
+
+// partial: clslam_dispconv_wgrad_blocks(B*h*w) * (9*ch+1) floats; reduce with clslam_reduce_partials
+// (n = 9*ch+1: the 9*ch weight gradients [tap][c] followed by the bias gradient).
+extern "C" int clslam_dispconv_wgrad(const float* dz, const float* x, float* partial, int batch, int h, int wd, int ch,
+                                     void* stream) {
+    CLSLAM_REQUIRE(dz && x && partial && ch % 4 == 0 && ch <= 256, "dispconv_wgrad: bad args");
+    const int pixels = batch * h * wd;
+    const int blocks = clslam_dispconv_wgrad_blocks(pixels);
+    const int ppb = cdiv(std::max(pixels, 1), blocks);
+    hipLaunchKernelGGL(dispconv_wgrad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dz, x,
+                       partial, batch, h, wd, ch, ppb);
+    return check_launch("dispconv_wgrad");
+}
+
+extern "C" int clslam_pose_head_fwd(const float* x, const float* w2, const float* b2, float* mean, float* pose, int n,
+                                    int hw, void* stream) {
+    CLSLAM_REQUIRE(x && w2 && b2 && mean && pose, "pose_head_fwd: null");
+    if (!n) return CLSLAM_OK;
+    hipLaunchKernelGGL(pose_head_fwd_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, x, w2, b2, mean, pose, hw);
+    return check_launch("pose_head_fwd");
+}
+
+extern "C" int clslam_pose_head_bwd(const float* dpose, const float* x, const float* w2, const float* mean, float* dz1,
+                                    float* dw2, float* db2, int n, int hw, float grad_scale, void* stream) {
+    CLSLAM_REQUIRE(dpose && x && w2 && mean && dz1 && dw2 && db2, "pose_head_bwd: null");
+    hipLaunchKernelGGL(pose_head_bwd_kernel, dim3(n + 1), dim3(256), 0, (hipStream_t)stream, dpose, x, w2, mean, dz1, dw2,
+                       db2, n, hw, grad_scale);
+    return check_launch("pose_head_bwd");
+}

@@ -96,6 +96,37 @@ int clslam_reduce_partials(const float* partial, float* out, size_t n, int split
 int clslam_colsum_blocks(int rows);
 int clslam_colsum(const float* x, float* partial, int rows, int ch, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Encoder stem (frozen): (x-0.45)/0.225 -> conv7x7 s2 p3 -> eval BN -> ReLU, and maxpool 3x3 s2 p1.
+ * Replaces networks/resnet_encoder.py:117-121.  img_a/img_b: planar (B,3,h,w) frames exactly as
+ * the sample dict holds them (img_b = second frame of the pose pair, dpp.py:951-955, or NULL);
+ * weight: (64, 3*num_images, 7, 7) in the checkpoint's OIHW order; out: NHWC (B,h/2,w/2,64).     */
+int clslam_stem_conv(const float* img_a, const float* img_b, const float* weight, const float* scale,
+                     const float* shift, float* out, int batch, int h, int w, int num_images, void* stream);
+int clslam_maxpool3x3s2(const float* in, float* out, int batch, int h, int w, int ch, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Disparity head: reflection-padded 3x3 conv C->1 + sigmoid (networks/depth_decoder.py:67-69) and
+ * its backward.  x NHWC (B,h,w,ch); w [9][ch]; disp / dz planar (B,h,w); dz = dL/d(pre-sigmoid).
+ * dispconv_bwd_data writes (accumulate=0) or adds (1) into the padded-domain gradient
+ * dxp (B,h+2,w+2,ch) that clslam_fold_act_grad consumes.                                        */
+int clslam_dispconv_fwd(const float* x, const float* w, const float* bias, float* disp, int batch, int h, int wd,
+                        int ch, void* stream);
+int clslam_dispconv_bwd_data(const float* dz, const float* w, float* dxp, int batch, int h, int wd, int ch,
+                             int accumulate, void* stream);
+int clslam_dispconv_wgrad_blocks(int pixels);
+int clslam_dispconv_wgrad(const float* dz, const float* x, float* partial, int batch, int h, int wd, int ch,
+                          void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Pose head: pose_2 (1x1, 256->12) + spatial mean + x0.01 (networks/pose_decoder.py:44-54) and
+ * its backward.  x: pose_1 output NHWC (n,hw,256) post-ReLU; pose (n,12); mean (n,256) is kept
+ * for the backward; dz1 = dL/d(pre-ReLU pose_1 output).                                         */
+int clslam_pose_head_fwd(const float* x, const float* w2, const float* b2, float* mean, float* pose, int n, int hw,
+                         void* stream);
+int clslam_pose_head_bwd(const float* dpose, const float* x, const float* w2, const float* mean, float* dz1,
+                         float* dw2, float* db2, int n, int hw, float grad_scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
