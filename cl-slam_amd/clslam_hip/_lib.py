@@ -28,6 +28,14 @@ class ConvDesc(C.Structure):
                 ('act', i32), ('config', i32), ('actgrad_src', fptr), ('actgrad_kind', i32)]
 
 
+class LossDesc(C.Structure):
+    _fields_ = [('partial', fptr * 4), ('disp', fptr * 4), ('rgb0', fptr * 4), ('means', fptr * 4),
+                ('pose', fptr), ('dist0', fptr), ('dist1', fptr), ('sample_w', fptr), ('smooth_w', fptr),
+                ('losses', fptr), ('smooth_aux', fptr),
+                ('batch', i32), ('nblk', i32), ('H', i32), ('W', i32), ('n_smooth', i32),
+                ('smooth_scale', C.c_float), ('vel_scale', C.c_float)]
+
+
 # name -> argtypes (restype is always int unless listed in _RESTYPES)
 _SIGNATURES = {
     'clslam_version': [],
@@ -48,6 +56,19 @@ _SIGNATURES = {
     'clslam_dispconv_wgrad': [fptr, fptr, fptr, i32, i32, i32, i32, C.c_void_p],
     'clslam_pose_head_fwd': [fptr, fptr, fptr, fptr, fptr, i32, i32, C.c_void_p],
     'clslam_pose_head_bwd': [fptr, fptr, fptr, fptr, fptr, fptr, fptr, i32, i32, C.c_float, C.c_void_p],
+    'clslam_pose_to_proj': [fptr, fptr, fptr, fptr, i32, C.c_void_p],
+    'clslam_warp_fwd': [fptr, i32, i32, fptr, fptr, fptr, fptr, fptr, fptr, i32, i32, i32, C.c_float, C.c_float, C.c_void_p],
+    'clslam_warp_bwd_blocks': [i32, i32],
+    'clslam_warp_bwd': [fptr, fptr, i32, i32, fptr, fptr, fptr, fptr, fptr, fptr, i32, i32, i32, C.c_float, C.c_float,
+                        C.c_void_p],
+    'clslam_pose_bwd': [fptr, i32, i32, fptr, fptr, fptr, fptr, fptr, C.c_float, fptr, i32, C.c_void_p],
+    'clslam_photo_map': [fptr, fptr, fptr, fptr, i32, i32, i32, i32, C.c_void_p],
+    'clslam_automask_blocks': [i32, i32],
+    'clslam_automask': [fptr, fptr, fptr, fptr, fptr, i32, i32, i32, C.c_void_p],
+    'clslam_disp_mean': [fptr, fptr, i32, i32, C.c_void_p],
+    'clslam_loss_finalize': [C.POINTER(LossDesc), C.c_void_p],
+    'clslam_photo_grad': [fptr, fptr, fptr, fptr, fptr, fptr, i32, i32, i32, C.c_void_p],
+    'clslam_disp_grad': [fptr, fptr, fptr, i32, fptr, i32, i32, i32, i32, i32, C.c_void_p],
 }
 _RESTYPES = {'clslam_last_error': C.c_char_p}
 

@@ -25,6 +25,16 @@ def _p(t: Optional[torch.Tensor]):
     return t.data_ptr()
 
 
+def _pa(t: Optional[torch.Tensor], dtype):
+    """pointer of a contiguous tensor of another dtype (uint8 selection maps, float64 distances)"""
+    if t is None:
+        return None
+    lib = _lib.get_lib()
+    if t.device.type != lib.device_type or t.dtype != dtype or not t.is_contiguous():
+        raise _lib.ClslamError(f'expected contiguous {dtype} on {lib.device_type}, got {t.dtype} on {t.device}')
+    return t.data_ptr()
+
+
 def conv2d(src_a, weight, out, *, src_b=None, scale=None, shift=None, residual=None, ksize=3, stride=1,
            pad=None, pad_mode=PAD_ZERO, upsample_a=False, act=ACT_NONE, config=-1, actgrad_src=None,
            actgrad_kind=ACT_NONE):
@@ -141,3 +151,79 @@ def pose_head_bwd(dpose, x, w2, mean, dz1, dw2, db2, grad_scale=1.0):
     N, H, W, _ = x.shape
     _lib.get_lib().call('clslam_pose_head_bwd', _p(dpose), _p(x), _p(w2), _p(mean), _p(dz1), _p(dw2), _p(db2),
                         N, H * W, grad_scale, _stream(x))
+
+
+def _nd(v):
+    return -1.0 if v is None else float(v)
+
+
+def pose_to_proj(pose, kmat, cam_t_cam, proj):
+    B = kmat.shape[0]
+    _lib.get_lib().call('clslam_pose_to_proj', _p(pose), _p(kmat), _p(cam_t_cam), _p(proj), B, _stream(pose))
+
+
+def warp_fwd(disp_s, src_m1, src_p1, inv_k, proj, depth, warped, min_depth, max_depth):
+    B, H, W = depth.shape[0], depth.shape[-2], depth.shape[-1]
+    h, w = disp_s.shape[-2:]
+    _lib.get_lib().call('clslam_warp_fwd', _p(disp_s), h, w, _p(src_m1), _p(src_p1), _p(inv_k), _p(proj), _p(depth),
+                        _p(warped), B, H, W, _nd(min_depth), _nd(max_depth), _stream(depth))
+
+
+def warp_bwd_blocks(H, W) -> int:
+    return _lib.get_lib().cdll.clslam_warp_bwd_blocks(H, W)
+
+
+def warp_bwd(dpred, disp_s, src_m1, src_p1, inv_k, proj, ddisp_up, dp_partial, min_depth, max_depth):
+    B, H, W = ddisp_up.shape[0], ddisp_up.shape[-2], ddisp_up.shape[-1]
+    h, w = disp_s.shape[-2:]
+    _lib.get_lib().call('clslam_warp_bwd', _p(dpred), _p(disp_s), h, w, _p(src_m1), _p(src_p1), _p(inv_k), _p(proj),
+                        _p(ddisp_up), _p(dp_partial), B, H, W, _nd(min_depth), _nd(max_depth), _stream(dpred))
+
+
+def pose_bwd(dp_partial, nscale, nblk, pose, kmat, dist0, dist1, sample_w, vel_scale, dpose):
+    B = kmat.shape[0]
+    _lib.get_lib().call('clslam_pose_bwd', _p(dp_partial), nscale, nblk, _p(pose), _p(kmat), _pa(dist0, torch.float64),
+                        _pa(dist1, torch.float64), _p(sample_w), float(vel_scale or 0.0), _p(dpose), B, _stream(pose))
+
+
+def photo_map(pred, target, out_map, coef, npred, batch, H, W):
+    _lib.get_lib().call('clslam_photo_map', _p(pred), _p(target), _p(out_map), _p(coef), npred, batch, H, W,
+                        _stream(out_map))
+
+
+def automask_blocks(H, W) -> int:
+    return _lib.get_lib().cdll.clslam_automask_blocks(H, W)
+
+
+def automask(idmap, noise, rpmap, sel, partial, batch, H, W):
+    _lib.get_lib().call('clslam_automask', _p(idmap), _p(noise), _p(rpmap), _pa(sel, torch.uint8), _p(partial), batch,
+                        H, W, _stream(idmap))
+
+
+def disp_mean(disp, means):
+    B = disp.shape[0]
+    _lib.get_lib().call('clslam_disp_mean', _p(disp), _p(means), B, disp.numel() // B, _stream(disp))
+
+
+def loss_finalize(partials, disps, rgb0s, means, pose, dist0, dist1, sample_w, smooth_w, losses, smooth_aux, batch,
+                  nblk, H, W, n_smooth, smooth_scale, vel_scale):
+    d = _lib.LossDesc()
+    for s in range(4):
+        d.partial[s] = _p(partials[s]); d.disp[s] = _p(disps[s]); d.rgb0[s] = _p(rgb0s[s]); d.means[s] = _p(means[s])
+    d.pose = _p(pose)
+    d.dist0 = _pa(dist0, torch.float64); d.dist1 = _pa(dist1, torch.float64)
+    d.sample_w = _p(sample_w); d.smooth_w = _p(smooth_w); d.losses = _p(losses); d.smooth_aux = _p(smooth_aux)
+    d.batch, d.nblk, d.H, d.W, d.n_smooth = batch, nblk, H, W, n_smooth
+    d.smooth_scale, d.vel_scale = float(smooth_scale), float(vel_scale or 0.0)
+    _lib.get_lib().call('clslam_loss_finalize', C.byref(d), _stream(losses))
+
+
+def photo_grad(sel, coef, pred, target, sample_w, dpred, batch, H, W):
+    _lib.get_lib().call('clslam_photo_grad', _pa(sel, torch.uint8), _p(coef), _p(pred), _p(target), _p(sample_w),
+                        _p(dpred), batch, H, W, _stream(dpred))
+
+
+def disp_grad(ddisp_up, disp, smooth_aux, n_smooth, dz, H, W):
+    B, h, w = disp.shape[0], disp.shape[-2], disp.shape[-1]
+    _lib.get_lib().call('clslam_disp_grad', _p(ddisp_up), _p(disp), _p(smooth_aux), n_smooth, _p(dz), B, h, w, H, W,
+                        _stream(dz))

@@ -1,0 +1,381 @@
+// K8/K9/K13(geometry half)/K14: pose -> matrices, view synthesis and their backward.
+//
+// Reference: depth_pose_prediction/utils.py:34-117 (axis-angle/translation -> 4x4, `invert` for
+// frame -1), networks/layers.py:51-104 (BackprojectDepth, Project3D), utils.py:120-142
+// (disp_to_depth), dpp.py:986-1017 (bilinear upsample of the disparity to full resolution,
+// F.grid_sample(bilinear, border, align_corners=True) of the UN-augmented scale-0 source frame with
+// scale-0 intrinsics).  All of it is HBM-bound per-pixel work: one thread per pixel, planar NCHW
+// images exactly as the reference's sample/output dicts hold them, coalesced along x.
+#include "common.h"
+
+namespace clslam {
+
+// ------------------------------------------------------------------------------------------------
+// One thread per (frame fi, sample b).  pose rows n = fi*B + b hold [axis_angle(3), translation(3), ...].
+__global__ void pose_to_proj_kernel(const float* __restrict__ pose, const float* __restrict__ Kmat, float* __restrict__ T,
+                                    float* __restrict__ P, int B) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= 2 * B) return;
+    const int fi = n / B, b = n - fi * B;
+    const bool invert = (fi == 0);  // frame -1 (dpp.py:970-973)
+    const float* ps = pose + (size_t)n * 12;
+    const float vx = ps[0], vy = ps[1], vz = ps[2];
+    float t0 = ps[3], t1 = ps[4], t2 = ps[5];
+    const float angle = sqrtf(vx * vx + vy * vy + vz * vz);
+    const float inv = angle + 1e-7f;
+    const float x = vx / inv, y = vy / inv, z = vz / inv;
+    const float ca = cosf(angle), sa = sinf(angle), C = 1.f - ca;
+    const float xs = x * sa, ys = y * sa, zs = z * sa;
+    const float xC = x * C, yC = y * C, zC = z * C;
+    const float xyC = x * yC, yzC = y * zC, zxC = z * xC;
+    float R[3][3] = {{x * xC + ca, xyC - zs, zxC + ys}, {xyC + zs, y * yC + ca, yzC - xs}, {zxC - ys, yzC + xs, z * zC + ca}};
+    float M[4][4];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) M[i][j] = (i == j) ? 1.f : 0.f;
+    if (invert) {
+        t0 = -t0; t1 = -t1; t2 = -t2;
+        for (int i = 0; i < 3; ++i) {
+            for (int j = 0; j < 3; ++j) M[i][j] = R[j][i];
+            M[i][3] = R[0][i] * t0 + R[1][i] * t1 + R[2][i] * t2;
+        }
+    } else {
+        for (int i = 0; i < 3; ++i) {
+            for (int j = 0; j < 3; ++j) M[i][j] = R[i][j];
+        }
+        M[0][3] = t0; M[1][3] = t1; M[2][3] = t2;
+    }
+    float* To = T + (size_t)n * 16;
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) To[i * 4 + j] = M[i][j];
+    const float* K = Kmat + (size_t)b * 16;
+    float* Po = P + (size_t)n * 12;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 4; ++j) {
+            float s = 0.f;
+            for (int k = 0; k < 4; ++k) s = fmaf(K[i * 4 + k], M[k][j], s);
+            Po[i * 4 + j] = s;
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
+struct WarpGeom {
+    float depth, disp, u, v;          // forward values
+    float X[3];                       // back-projected point
+    float cam[3];                     // Kinv[:3,:3] * [x,y,1]
+};
+
+__device__ __forceinline__ float upsample_disp(const float* __restrict__ d, int h, int w, int H, int W, int y, int x) {
+    // F.interpolate(..., mode='bilinear', align_corners=False): src = (dst+0.5)*in/out - 0.5, clamped at 0
+    const float ry = (float)h / (float)H, rx = (float)w / (float)W;
+    float sy = ry * ((float)y + 0.5f) - 0.5f; if (sy < 0.f) sy = 0.f;
+    float sx = rx * ((float)x + 0.5f) - 0.5f; if (sx < 0.f) sx = 0.f;
+    const int y0 = (int)sy, x0 = (int)sx;
+    const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
+    const float ly = sy - (float)y0, lx = sx - (float)x0;
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    return hy * (hx * d[y0 * w + x0] + lx * d[y0 * w + x1]) + ly * (hx * d[y1 * w + x0] + lx * d[y1 * w + x1]);
+}
+
+__device__ __forceinline__ float disp_to_depth_dev(float disp, float dmin_a, float dmin_b, int mode) {
+    // mode 0: 1/disp; 1: min_depth/disp (a = min_depth); 2: 1/(a + b*disp) (a = 1/max, b = 1/min - 1/max)
+    if (mode == 0) return 1.f / disp;
+    if (mode == 1) return dmin_a / disp;
+    return 1.f / (dmin_a + dmin_b * disp);
+}
+
+struct Sample {
+    float ix, iy;       // clipped pixel coordinates
+    float mx, my;       // gradient multipliers of the clip (0 at / outside the border)
+    int x0, y0;         // floor
+};
+
+__device__ __forceinline__ Sample sample_coords(float u, float v, int H, int W) {
+    // Project3D normalisation (layers.py:101-103) followed by grid_sample's un-normalisation
+    // (align_corners=True) and border clipping.
+    Sample s;
+    const float gx = (u / (float)(W - 1) - 0.5f) * 2.f;
+    const float gy = (v / (float)(H - 1) - 0.5f) * 2.f;
+    float ix = ((gx + 1.f) / 2.f) * (float)(W - 1);
+    float iy = ((gy + 1.f) / 2.f) * (float)(H - 1);
+    s.mx = 1.f; s.my = 1.f;
+    if (!(ix > 0.f)) { ix = 0.f; s.mx = 0.f; } else if (ix >= (float)(W - 1)) { ix = (float)(W - 1); s.mx = 0.f; }
+    if (!(iy > 0.f)) { iy = 0.f; s.my = 0.f; } else if (iy >= (float)(H - 1)) { iy = (float)(H - 1); s.my = 0.f; }
+    s.ix = ix; s.iy = iy;
+    s.x0 = (int)floorf(ix); s.y0 = (int)floorf(iy);
+    return s;
+}
+
+// depth[b,y,x] and warped[fi,b,c,y,x] for one scale.
+__global__ __launch_bounds__(256) void warp_fwd_kernel(const float* __restrict__ disp_s, int h, int w,
+                                                       const float* __restrict__ src_m1, const float* __restrict__ src_p1,
+                                                       const float* __restrict__ Kinv, const float* __restrict__ P,
+                                                       float* __restrict__ depth, float* __restrict__ warped, int B, int H,
+                                                       int W, float da, float db, int dmode) {
+    const size_t total = (size_t)B * H * W;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(idx % W), y = (int)((idx / W) % H), b = (int)(idx / ((size_t)W * H));
+        const float disp = upsample_disp(disp_s + (size_t)b * h * w, h, w, H, W, y, x);
+        const float dep = disp_to_depth_dev(disp, da, db, dmode);
+        depth[idx] = dep;
+        const float* Ki = Kinv + (size_t)b * 16;
+        const float fx = (float)x, fy = (float)y;
+        float X[3];
+        for (int i = 0; i < 3; ++i) X[i] = dep * (Ki[i * 4 + 0] * fx + Ki[i * 4 + 1] * fy + Ki[i * 4 + 2]);
+        for (int fi = 0; fi < 2; ++fi) {
+            const float* Pm = P + ((size_t)fi * B + b) * 12;
+            float p[3];
+            for (int i = 0; i < 3; ++i) p[i] = Pm[i * 4 + 0] * X[0] + Pm[i * 4 + 1] * X[1] + Pm[i * 4 + 2] * X[2] + Pm[i * 4 + 3];
+            const float den = p[2] + 1e-7f;
+            const Sample s = sample_coords(p[0] / den, p[1] / den, H, W);
+            const float wx1 = s.ix - (float)s.x0, wy1 = s.iy - (float)s.y0;
+            const float wx0 = (float)(s.x0 + 1) - s.ix, wy0 = (float)(s.y0 + 1) - s.iy;
+            const bool x1ok = s.x0 + 1 < W, y1ok = s.y0 + 1 < H;
+            const float* src = (fi == 0 ? src_m1 : src_p1) + (size_t)b * 3 * H * W;
+            for (int c = 0; c < 3; ++c) {
+                const float* pl = src + (size_t)c * H * W;
+                float v = pl[s.y0 * W + s.x0] * (wx0 * wy0);
+                if (x1ok) v += pl[s.y0 * W + s.x0 + 1] * (wx1 * wy0);
+                if (y1ok) v += pl[(s.y0 + 1) * W + s.x0] * (wx0 * wy1);
+                if (x1ok && y1ok) v += pl[(s.y0 + 1) * W + s.x0 + 1] * (wx1 * wy1);
+                warped[(((size_t)fi * B + b) * 3 + c) * H * W + (size_t)y * W + x] = v;
+            }
+        }
+    }
+}
+
+// Backward of warp_fwd for one scale.  dpred[fi,b,c,y,x] = dL/d warped.  Writes
+//   ddisp_up[b,y,x] = dL/d(upsampled disparity)   and   dP_partial[b][blk][fi*12+k] (block sums).
+__global__ __launch_bounds__(256) void warp_bwd_kernel(const float* __restrict__ dpred, const float* __restrict__ disp_s,
+                                                       int h, int w, const float* __restrict__ src_m1,
+                                                       const float* __restrict__ src_p1, const float* __restrict__ Kinv,
+                                                       const float* __restrict__ P, float* __restrict__ ddisp_up,
+                                                       float* __restrict__ dP_partial, int B, int H, int W, float da, float db,
+                                                       int dmode, int pix_per_block) {
+    __shared__ float red[4][24];
+    const int b = blockIdx.y;
+    const int HW = H * W;
+    const int p0 = blockIdx.x * pix_per_block, p1 = min(HW, p0 + pix_per_block);
+    float dPacc[24];
+#pragma unroll
+    for (int k = 0; k < 24; ++k) dPacc[k] = 0.f;
+    const float* Ki = Kinv + (size_t)b * 16;
+    for (int pi = p0 + (int)threadIdx.x; pi < p1; pi += 256) {
+        const int x = pi % W, y = pi / W;
+        const float disp = upsample_disp(disp_s + (size_t)b * h * w, h, w, H, W, y, x);
+        const float dep = disp_to_depth_dev(disp, da, db, dmode);
+        const float fx = (float)x, fy = (float)y;
+        float cam[3], X[3];
+        for (int i = 0; i < 3; ++i) { cam[i] = Ki[i * 4 + 0] * fx + Ki[i * 4 + 1] * fy + Ki[i * 4 + 2]; X[i] = dep * cam[i]; }
+        float ddepth = 0.f;
+        for (int fi = 0; fi < 2; ++fi) {
+            const float* Pm = P + ((size_t)fi * B + b) * 12;
+            float p[3];
+            for (int i = 0; i < 3; ++i) p[i] = Pm[i * 4 + 0] * X[0] + Pm[i * 4 + 1] * X[1] + Pm[i * 4 + 2] * X[2] + Pm[i * 4 + 3];
+            const float den = p[2] + 1e-7f;
+            const float u = p[0] / den, v = p[1] / den;
+            const Sample s = sample_coords(u, v, H, W);
+            const float wx1 = s.ix - (float)s.x0, wy1 = s.iy - (float)s.y0;
+            const float wx0 = (float)(s.x0 + 1) - s.ix, wy0 = (float)(s.y0 + 1) - s.iy;
+            const bool x1ok = s.x0 + 1 < W, y1ok = s.y0 + 1 < H;
+            const float* src = (fi == 0 ? src_m1 : src_p1) + (size_t)b * 3 * HW;
+            float gix = 0.f, giy = 0.f;
+            for (int c = 0; c < 3; ++c) {
+                const float g = dpred[(((size_t)fi * B + b) * 3 + c) * HW + pi];
+                const float* pl = src + (size_t)c * HW;
+                const float nw = pl[s.y0 * W + s.x0];
+                const float ne = x1ok ? pl[s.y0 * W + s.x0 + 1] : 0.f;
+                const float sw = y1ok ? pl[(s.y0 + 1) * W + s.x0] : 0.f;
+                const float se = (x1ok && y1ok) ? pl[(s.y0 + 1) * W + s.x0 + 1] : 0.f;
+                gix += g * (-nw * wy0 + ne * wy0 - sw * wy1 + se * wy1);
+                giy += g * (-nw * wx0 - ne * wx1 + sw * wx0 + se * wx1);
+            }
+            const float du = gix * s.mx, dv = giy * s.my;
+            float dp[3];
+            dp[0] = du / den;
+            dp[1] = dv / den;
+            dp[2] = -(du * u + dv * v) / den;
+            for (int i = 0; i < 3; ++i) {
+                dPacc[fi * 12 + i * 4 + 0] += dp[i] * X[0];
+                dPacc[fi * 12 + i * 4 + 1] += dp[i] * X[1];
+                dPacc[fi * 12 + i * 4 + 2] += dp[i] * X[2];
+                dPacc[fi * 12 + i * 4 + 3] += dp[i];
+            }
+            for (int j = 0; j < 3; ++j)
+                ddepth += (Pm[0 * 4 + j] * dp[0] + Pm[1 * 4 + j] * dp[1] + Pm[2 * 4 + j] * dp[2]) * cam[j];
+        }
+        float dd;
+        if (dmode == 2) dd = -db * dep * dep * ddepth;
+        else dd = -dep / disp * ddepth;
+        ddisp_up[(size_t)b * HW + pi] = dd;
+    }
+    // block reduction of the 24 dP entries (fixed order -> deterministic)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 24; ++k) {
+        const float s = wave_sum(dPacc[k]);
+        if (lane == 0) red[wave][k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 24)
+        dP_partial[((size_t)b * gridDim.x + blockIdx.x) * 24 + threadIdx.x] =
+            red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+// ------------------------------------------------------------------------------------------------
+// One block per sample b.  Phase 1: dP[fi][12] = sum over (scale, block) partials (10 row-lanes x 24
+// columns, fixed order).  Phase 2 (threads 0,1 = frame idx): the pose chain backward (autograd of
+// utils.py:34-117 and layers.py:94) plus the velocity-loss gradient (dpp.py:1125-1146).
+__global__ __launch_bounds__(256) void pose_bwd_kernel(const float* __restrict__ dP_partial, int nscale, int nblk,
+                                                       const float* __restrict__ pose, const float* __restrict__ Kmat,
+                                                       const double* __restrict__ dist0, const double* __restrict__ dist1,
+                                                       const float* __restrict__ sample_w, float vel_scale,
+                                                       float* __restrict__ dpose, int B) {
+    __shared__ float red[10][24];
+    __shared__ float dPs[24];
+    const int b = blockIdx.x;
+    {
+        const int k = threadIdx.x % 24, rl = threadIdx.x / 24;
+        if (rl < 10) {
+            float s = 0.f;
+            const int rows = nscale * nblk;
+            for (int r = rl; r < rows; r += 10) {
+                const int sc = r / nblk, blk = r - sc * nblk;
+                s += dP_partial[(((size_t)sc * B + b) * nblk + blk) * 24 + k];
+            }
+            red[rl][k] = s;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 24) {
+        float s = 0.f;
+        for (int r = 0; r < 10; ++r) s += red[r][threadIdx.x];
+        dPs[threadIdx.x] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x >= 2) return;
+    const int fi = threadIdx.x;
+    const int n = fi * B + b;
+    float dP[12];
+    for (int k = 0; k < 12; ++k) dP[k] = dPs[fi * 12 + k];
+    const float* K = Kmat + (size_t)b * 16;
+    // dM[k][j] = sum_{i<3} K[i][k] * dP[i][j]
+    float dM[4][4];
+    for (int k = 0; k < 4; ++k)
+        for (int j = 0; j < 4; ++j) dM[k][j] = K[0 * 4 + k] * dP[0 * 4 + j] + K[1 * 4 + k] * dP[1 * 4 + j] + K[2 * 4 + k] * dP[2 * 4 + j];
+    const float* ps = pose + (size_t)n * 12;
+    const float vx = ps[0], vy = ps[1], vz = ps[2];
+    const float t[3] = {ps[3], ps[4], ps[5]};
+    const float angle = sqrtf(vx * vx + vy * vy + vz * vz);
+    const float inv = angle + 1e-7f;
+    const float x = vx / inv, y = vy / inv, z = vz / inv;
+    const float ca = cosf(angle), sa = sinf(angle), C = 1.f - ca;
+    const float R[3][3] = {{x * x * C + ca, x * y * C - z * sa, z * x * C + y * sa},
+                           {x * y * C + z * sa, y * y * C + ca, y * z * C - x * sa},
+                           {z * x * C - y * sa, y * z * C + x * sa, z * z * C + ca}};
+    float G[3][3], dt[3];
+    if (fi == 0) {  // inverted: M3 = R^T, Mt[i] = -sum_k R[k][i] t[k]
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) G[i][j] = dM[j][i];
+        for (int k = 0; k < 3; ++k) {
+            float s = 0.f;
+            for (int i = 0; i < 3; ++i) {
+                G[k][i] += -t[k] * dM[i][3];
+                s += R[k][i] * dM[i][3];
+            }
+            dt[k] = -s;
+        }
+    } else {
+        for (int i = 0; i < 3; ++i) {
+            for (int j = 0; j < 3; ++j) G[i][j] = dM[i][j];
+            dt[i] = dM[i][3];
+        }
+    }
+    const float xC = x * C, yC = y * C, zC = z * C;
+    const float s01 = G[0][1] + G[1][0], s02 = G[0][2] + G[2][0], s12 = G[1][2] + G[2][1];
+    float dx = G[0][0] * 2.f * xC + s01 * yC + s02 * zC + (G[2][1] - G[1][2]) * sa;
+    float dy = G[1][1] * 2.f * yC + s01 * xC + s12 * zC + (G[0][2] - G[2][0]) * sa;
+    float dz = G[2][2] * 2.f * zC + s02 * xC + s12 * yC + (G[1][0] - G[0][1]) * sa;
+    const float dC = G[0][0] * x * x + G[1][1] * y * y + G[2][2] * z * z + s01 * x * y + s02 * z * x + s12 * y * z;
+    const float dca = G[0][0] + G[1][1] + G[2][2] - dC;
+    const float dsa = (G[1][0] - G[0][1]) * z + (G[0][2] - G[2][0]) * y + (G[2][1] - G[1][2]) * x;
+    float dtheta = -sa * dca + ca * dsa;
+    dtheta += -(dx * vx + dy * vy + dz * vz) / (inv * inv);
+    float dv[3] = {dx / inv, dy / inv, dz / inv};
+    if (angle > 0.f) { dv[0] += dtheta * vx / angle; dv[1] += dtheta * vy / angle; dv[2] += dtheta * vz / angle; }
+    // velocity loss: frame idx 0 (translation 0->-1) pairs with relative_distance(0), idx 1 with (1)
+    if (vel_scale > 0.f) {
+        const double gt = fabs(fi == 0 ? dist0[b] : dist1[b]);
+        const float nrm = sqrtf(t[0] * t[0] + t[1] * t[1] + t[2] * t[2]);
+        const double diff = (double)nrm - gt;
+        const float sg = diff > 0.0 ? 1.f : (diff < 0.0 ? -1.f : 0.f);
+        if (nrm > 0.f) {
+            const float coef = sample_w[b] * vel_scale * 0.5f * sg / nrm;
+            dt[0] += coef * t[0]; dt[1] += coef * t[1]; dt[2] += coef * t[2];
+        }
+    }
+    float* o = dpose + (size_t)n * 12;
+    o[0] = dv[0]; o[1] = dv[1]; o[2] = dv[2];
+    o[3] = dt[0]; o[4] = dt[1]; o[5] = dt[2];
+    for (int k = 6; k < 12; ++k) o[k] = 0.f;
+}
+
+}  // namespace clslam
+
+using namespace clslam;
+
+static void depth_mode(float min_depth, float max_depth, float* a, float* b, int* mode) {
+    // utils.py:120-142 ; a value <= 0 stands for None
+    if (min_depth <= 0.f && max_depth <= 0.f) { *mode = 0; *a = 0.f; *b = 0.f; }
+    else if (max_depth <= 0.f) { *mode = 1; *a = min_depth; *b = 0.f; }
+    else { *mode = 2; *a = 1.f / max_depth; *b = 1.f / min_depth - 1.f / max_depth; }
+}
+
+extern "C" int clslam_pose_to_proj(const float* pose, const float* kmat, float* cam_t_cam, float* proj, int batch,
+                                   void* stream) {
+    CLSLAM_REQUIRE(pose && kmat && cam_t_cam && proj, "pose_to_proj: null");
+    if (!batch) return CLSLAM_OK;
+    hipLaunchKernelGGL(pose_to_proj_kernel, dim3(cdiv(2 * batch, 64)), dim3(64), 0, (hipStream_t)stream, pose, kmat,
+                       cam_t_cam, proj, batch);
+    return check_launch("pose_to_proj");
+}
+
+extern "C" int clslam_warp_fwd(const float* disp_s, int h, int w, const float* src_m1, const float* src_p1,
+                               const float* inv_k, const float* proj, float* depth, float* warped, int batch, int H, int W,
+                               float min_depth, float max_depth, void* stream) {
+    CLSLAM_REQUIRE(disp_s && src_m1 && src_p1 && inv_k && proj && depth && warped, "warp_fwd: null");
+    CLSLAM_REQUIRE(!(min_depth <= 0.f && max_depth > 0.f), "warp_fwd: min_depth is None");
+    float a, b; int mode;
+    depth_mode(min_depth, max_depth, &a, &b, &mode);
+    const size_t total = (size_t)batch * H * W;
+    if (!total) return CLSLAM_OK;
+    hipLaunchKernelGGL(warp_fwd_kernel, dim3((unsigned)std::min<size_t>(8192, (total + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, disp_s, h, w, src_m1, src_p1, inv_k, proj, depth, warped, batch, H, W, a, b, mode);
+    return check_launch("warp_fwd");
+}
+
+extern "C" int clslam_warp_bwd_blocks(int H, int W) { return std::max(1, std::min(256, cdiv(H * W, 1024))); }
+
+extern "C" int clslam_warp_bwd(const float* dpred, const float* disp_s, int h, int w, const float* src_m1,
+                               const float* src_p1, const float* inv_k, const float* proj, float* ddisp_up, float* dp_partial,
+                               int batch, int H, int W, float min_depth, float max_depth, void* stream) {
+    CLSLAM_REQUIRE(dpred && disp_s && src_m1 && src_p1 && inv_k && proj && ddisp_up && dp_partial, "warp_bwd: null");
+    float a, b; int mode;
+    depth_mode(min_depth, max_depth, &a, &b, &mode);
+    if (!batch) return CLSLAM_OK;
+    const int nblk = clslam_warp_bwd_blocks(H, W);
+    const int ppb = cdiv(H * W, nblk);
+    hipLaunchKernelGGL(warp_bwd_kernel, dim3(nblk, batch), dim3(256), 0, (hipStream_t)stream, dpred, disp_s, h, w, src_m1,
+                       src_p1, inv_k, proj, ddisp_up, dp_partial, batch, H, W, a, b, mode, ppb);
+    return check_launch("warp_bwd");
+}
+
+extern "C" int clslam_pose_bwd(const float* dp_partial, int nscale, int nblk, const float* pose, const float* kmat,
+                               const double* dist0, const double* dist1, const float* sample_w, float vel_scale,
+                               float* dpose, int batch, void* stream) {
+    CLSLAM_REQUIRE(dp_partial && pose && kmat && dpose && sample_w, "pose_bwd: null");
+    CLSLAM_REQUIRE(vel_scale <= 0.f || (dist0 && dist1), "pose_bwd: distances missing");
+    if (!batch) return CLSLAM_OK;
+    hipLaunchKernelGGL(pose_bwd_kernel, dim3(batch), dim3(256), 0, (hipStream_t)stream, dp_partial, nscale, nblk,
+                       pose, kmat, dist0, dist1, sample_w, vel_scale, dpose, batch);
+    return check_launch("pose_bwd");
+}

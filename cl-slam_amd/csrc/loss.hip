@@ -1,0 +1,380 @@
+// K10/K11/K12/K13(photometric half): SSIM + L1 photometric loss with auto-masking /
+// min-reprojection, the smoothness term (reference behaviour incl. its flattening quirk), the
+// velocity term, and the backward of all of it down to dL/d(warped image) and dL/d(sigmoid input).
+//
+// Reference: networks/layers.py:107-137 (SSIM: 3x3 box means on a ReflectionPad2d(1) image),
+// dpp.py:1178-1192 (0.85*mean_c SSIM + 0.15*mean_c L1), dpp.py:1038-1076 (identity losses + 1e-5
+// noise, min over [id(-1), id(+1), reproj(-1), reproj(+1)], mean over W then H, sample weights),
+// dpp.py:1084-1101 (mean-normalised disparity, smoothness x 1e-3/2^s, sum/4),
+// dpp.py:1148-1176 (smoothness: masked_select flattens the batch, so term i is the single flat
+// element i of sample 0's gradient maps -- SURVEY.md 0.3), dpp.py:1105-1112 and 1125-1146
+// (velocity), autograd for the backward.  HBM-bound stencil / pointwise kernels on planar images.
+#include "common.h"
+
+namespace clslam {
+
+__device__ __forceinline__ int refl(int i, int n) { return reflect_idx(i, n); }
+
+// ------------------------------------------------------------------------------------------------
+// map[n,y,x] = 0.85*mean_c ssim_c + 0.15*mean_c |t-p|  for pred image n (N = npred images, each
+// (3,H,W)) against target image (n % B).  When coef != NULL also stores, per channel c, the three
+// coefficients (alpha, beta, gamma) of d map / d pred_window_element = alpha + beta*x_r + gamma*y_r
+// (SSIM part only; the L1 part is recomputed in photo_grad) as coef[n][c*3+{0,1,2}][y][x].
+__global__ __launch_bounds__(256) void photo_map_kernel(const float* __restrict__ pred, const float* __restrict__ target,
+                                                        float* __restrict__ map, float* __restrict__ coef, int N, int B,
+                                                        int H, int W) {
+    const float C1 = 0.0001f, C2 = 0.0009f;
+    const size_t HW = (size_t)H * W;
+    const size_t total = (size_t)N * HW;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(idx % W), y = (int)((idx / W) % H), n = (int)(idx / HW);
+        const int b = n % B;
+        int ys[3], xs[3];
+        for (int k = 0; k < 3; ++k) { ys[k] = refl(y + k - 1, H); xs[k] = refl(x + k - 1, W); }
+        float ssim_sum = 0.f, l1_sum = 0.f;
+        for (int c = 0; c < 3; ++c) {
+            const float* pp = pred + ((size_t)n * 3 + c) * HW;
+            const float* tp = target + ((size_t)b * 3 + c) * HW;
+            float sx = 0.f, sy = 0.f, sxx = 0.f, syy = 0.f, sxy = 0.f;
+            for (int ky = 0; ky < 3; ++ky)
+                for (int kx = 0; kx < 3; ++kx) {
+                    const float xv = pp[ys[ky] * W + xs[kx]], yv = tp[ys[ky] * W + xs[kx]];
+                    sx += xv; sy += yv; sxx += xv * xv; syy += yv * yv; sxy += xv * yv;
+                }
+            const float mu_x = sx / 9.f, mu_y = sy / 9.f;
+            const float sig_x = sxx / 9.f - mu_x * mu_x, sig_y = syy / 9.f - mu_y * mu_y, sig_xy = sxy / 9.f - mu_x * mu_y;
+            const float n1 = 2.f * mu_x * mu_y + C1, n2 = 2.f * sig_xy + C2;
+            const float d1 = mu_x * mu_x + mu_y * mu_y + C1, d2 = sig_x + sig_y + C2;
+            const float d = d1 * d2;
+            const float S = (n1 * n2) / d;
+            const float raw = (1.f - S) / 2.f;
+            ssim_sum += fminf(fmaxf(raw, 0.f), 1.f);
+            l1_sum += fabsf(tp[y * W + x] - pp[y * W + x]);
+            if (coef) {
+                // d clamp((1-S)/2)/dS = -1/2 inside [0,1]; mean over 3 channels; 0.85 weight; /9 window
+                const float kf = (raw >= 0.f && raw <= 1.f) ? (0.85f / 3.f) * (-0.5f) / 9.f : 0.f;
+                const float A = (2.f * mu_y * (n2 - n1)) / d - S * (2.f * mu_x * (d2 - d1)) / d;
+                const float Bc = -2.f * S * d1 / d;
+                const float Cc = 2.f * n1 / d;
+                float* co = coef + ((size_t)n * 9 + c * 3) * HW + (size_t)y * W + x;
+                co[0] = kf * A; co[HW] = kf * Bc; co[2 * HW] = kf * Cc;
+            }
+        }
+        map[idx] = 0.85f * (ssim_sum / 3.f) + 0.15f * (l1_sum / 3.f);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// to_optimize = min over [id(-1)+noise0, id(+1)+noise1, reproj(-1), reproj(+1)]; sel = argmin;
+// partial[b][blk] = block sum of to_optimize.  grid (nblk, B).
+__global__ __launch_bounds__(256) void automask_kernel(const float* __restrict__ idmap, const float* __restrict__ noise,
+                                                       const float* __restrict__ rpmap, unsigned char* __restrict__ sel,
+                                                       float* __restrict__ partial, int B, int HW, int pix_per_block) {
+    __shared__ float red[4];
+    const int b = blockIdx.y;
+    const int p0 = blockIdx.x * pix_per_block, p1 = min(HW, p0 + pix_per_block);
+    float s = 0.f;
+    for (int p = p0 + (int)threadIdx.x; p < p1; p += 256) {
+        float c0 = idmap[((size_t)0 * B + b) * HW + p];
+        float c1 = idmap[((size_t)1 * B + b) * HW + p];
+        if (noise) { c0 += noise[((size_t)b * 2 + 0) * HW + p]; c1 += noise[((size_t)b * 2 + 1) * HW + p]; }
+        const float c2 = rpmap[((size_t)0 * B + b) * HW + p];
+        const float c3 = rpmap[((size_t)1 * B + b) * HW + p];
+        float m = c0; int k = 0;
+        if (c1 < m) { m = c1; k = 1; }
+        if (c2 < m) { m = c2; k = 2; }
+        if (c3 < m) { m = c3; k = 3; }
+        sel[(size_t)b * HW + p] = (unsigned char)k;
+        s += m;
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[(size_t)b * gridDim.x + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// mean of each sample's disparity map: means[b] (grid B, block 256)
+__global__ __launch_bounds__(256) void disp_mean_kernel(const float* __restrict__ disp, float* __restrict__ means, int hw) {
+    __shared__ float red[4];
+    const int b = blockIdx.x;
+    float s = 0.f;
+    for (int p = threadIdx.x; p < hw; p += 256) s += disp[(size_t)b * hw + p];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) means[b] = (red[0] + red[1] + red[2] + red[3]) / (float)hw;
+}
+
+struct FinalizeArgs {
+    const float* partial[4];     // [B][nblk] per scale
+    const float* disp[4];        // (B,h_s,w_s)
+    const float* rgb0[4];        // target pyramid ('rgb',0,s): (B,3,h_s,w_s)
+    const float* means[4];       // per-sample disparity means
+    const float* pose;           // (2B,12)
+    const double* dist0;         // |relative_distance(0)| source, (B)
+    const double* dist1;
+    const float* sample_w;       // (B) weights of the local samples
+    const float* smooth_w;       // (n_smooth) weights of the smoothness terms (reference quirk)
+    float* losses;               // [18]
+    float* smooth_aux;           // [4][2 + 2*n_smooth]: inv, dsum, gxs[i], gys[i]
+    int B, nblk, H, W, n_smooth;
+    float smooth_scale, vel_scale;
+};
+
+// One block of 256 threads.  Phase 1 spreads the O(B*nblk) partial sums, the O(B) smoothness terms
+// and the O(B) velocity terms over the lanes; phase 2 (thread 0) combines them in a fixed order.
+constexpr int FIN_MAXB = 64;
+__global__ __launch_bounds__(256) void loss_finalize_kernel(FinalizeArgs a) {
+    __shared__ float s_rl[4 * FIN_MAXB];      // weighted per-sample reprojection means
+    __shared__ float s_sm[4 * FIN_MAXB];      // weighted smoothness terms
+    __shared__ float s_ds[4 * FIN_MAXB];      // per-term contributions to sum_q D[q]*disp[q]
+    __shared__ float s_vel[FIN_MAXB];
+    const int tid = threadIdx.x;
+    const float invHW = 1.f / ((float)a.H * (float)a.W);
+    for (int pr = tid; pr < 4 * a.B; pr += 256) {
+        const int s = pr / a.B, b = pr - s * a.B;
+        float sum = 0.f;
+        for (int k = 0; k < a.nblk; ++k) sum += a.partial[s][(size_t)b * a.nblk + k];
+        s_rl[pr] = (sum * invHW) * a.sample_w[b];
+    }
+    // smoothness, reference quirk: term i = flat element i of the batch-flattened gradient maps
+    for (int pr = tid; pr < 4 * a.n_smooth; pr += 256) {
+        const int s = pr / a.n_smooth, i = pr - s * a.n_smooth;
+        const int h = a.H >> s, w = a.W >> s;
+        float* aux = a.smooth_aux + (size_t)s * (2 + 2 * a.n_smooth);
+        const float coefs = a.smooth_scale / (float)(1 << s) / 4.f;
+        // flat index i in (B,1,h,w-1) and (B,1,h-1,w)
+        const int bx = i / (h * (w - 1)), rx = i % (h * (w - 1)), yx = rx / (w - 1), xx = rx % (w - 1);
+        const int by = i / ((h - 1) * w), ry = i % ((h - 1) * w), yy = ry / w, xy = ry % w;
+        const float* dxp = a.disp[s] + (size_t)bx * h * w;
+        const float* dyp = a.disp[s] + (size_t)by * h * w;
+        const float mx = a.means[s][bx] + 1e-7f, my = a.means[s][by] + 1e-7f;
+        const float ax = dxp[yx * w + xx] / mx, bxv = dxp[yx * w + xx + 1] / mx;   // norm_disp (dpp.py:1087-1088)
+        const float ay = dyp[yy * w + xy] / my, byv = dyp[(yy + 1) * w + xy] / my;
+        float gix = 0.f, giy = 0.f;
+        for (int c = 0; c < 3; ++c) {
+            const float* im_x = a.rgb0[s] + ((size_t)bx * 3 + c) * h * w;
+            const float* im_y = a.rgb0[s] + ((size_t)by * 3 + c) * h * w;
+            gix += fabsf(im_x[yx * w + xx] - im_x[yx * w + xx + 1]);
+            giy += fabsf(im_y[yy * w + xy] - im_y[(yy + 1) * w + xy]);
+        }
+        const float ex = expf(-(gix / 3.f)), ey = expf(-(giy / 3.f));
+        s_sm[pr] = (fabsf(ax - bxv) * ex + fabsf(ay - byv) * ey) * a.smooth_w[i];
+        // d/d norm_disp bookkeeping for the backward (layout i < w-1 on sample 0 enforced by the host)
+        const float sgx = (ax > bxv) ? 1.f : (ax < bxv ? -1.f : 0.f);
+        const float sgy = (ay > byv) ? 1.f : (ay < byv ? -1.f : 0.f);
+        const float gxs = coefs * a.smooth_w[i] * ex * sgx;
+        const float gys = coefs * a.smooth_w[i] * ey * sgy;
+        aux[2 + i] = gxs;
+        aux[2 + a.n_smooth + i] = gys;
+        s_ds[pr] = gxs * (dxp[yx * w + xx] - dxp[yx * w + xx + 1]) + gys * (dyp[yy * w + xy] - dyp[(yy + 1) * w + xy]);
+    }
+    if (a.vel_scale > 0.f) {
+        for (int b = tid; b < a.B; b += 256) {
+            float acc = 0.f;
+            for (int fi = 0; fi < 2; ++fi) {
+                const float* t = a.pose + ((size_t)fi * a.B + b) * 12 + 3;
+                const float nrm = sqrtf(t[0] * t[0] + t[1] * t[1] + t[2] * t[2]);
+                const double gt = fabs(fi == 0 ? a.dist0[b] : a.dist1[b]);
+                acc = (float)((double)acc + fabs((double)nrm - gt));   // fp32 += fp64 (dpp.py:1142)
+            }
+            s_vel[b] = (a.vel_scale * (acc / 2.f)) * a.sample_w[b];
+        }
+    }
+    __syncthreads();
+    if (tid != 0) return;
+    float total = 0.f;
+    for (int s = 0; s < 4; ++s) {
+        const int h = a.H >> s, w = a.W >> s;
+        float rl = 0.f, sm = 0.f, dsum = 0.f;
+        for (int b = 0; b < a.B; ++b) rl += s_rl[s * a.B + b];
+        for (int i = 0; i < a.n_smooth; ++i) { sm += s_sm[s * a.n_smooth + i]; dsum += s_ds[s * a.n_smooth + i]; }
+        if (a.n_smooth > 0) {
+            float* aux = a.smooth_aux + (size_t)s * (2 + 2 * a.n_smooth);
+            const float inv0 = 1.f / (a.means[s][0] + 1e-7f);
+            aux[0] = inv0;
+            aux[1] = dsum * inv0 * inv0 / (float)(h * w);   // mean-normalisation feedback term
+        }
+        const float reg = a.smooth_scale / (float)(1 << s) * sm;
+        const float loss = rl + reg;
+        a.losses[s * 4 + 0] = rl; a.losses[s * 4 + 1] = sm; a.losses[s * 4 + 2] = reg; a.losses[s * 4 + 3] = loss;
+        total += loss;
+    }
+    total = total / 4.f;
+    float vel = 0.f;
+    if (a.vel_scale > 0.f) {
+        for (int b = 0; b < a.B; ++b) vel += s_vel[b];
+        total += vel;
+    }
+    a.losses[16] = vel;
+    a.losses[17] = total;
+}
+
+// ------------------------------------------------------------------------------------------------
+// dpred[fi,b,c,y,x] = dL/d warped for one scale: transposed SSIM stencil over the pixels whose
+// min picked reprojection fi (sel == 2+fi), reflection fold, plus the L1 term.
+__global__ __launch_bounds__(256) void photo_grad_kernel(const unsigned char* __restrict__ sel, const float* __restrict__ coef,
+                                                         const float* __restrict__ pred, const float* __restrict__ target,
+                                                         const float* __restrict__ sample_w, float* __restrict__ dpred,
+                                                         int B, int H, int W) {
+    const size_t HW = (size_t)H * W;
+    const size_t total = (size_t)2 * B * HW;
+    const float scale_all = 1.f / ((float)H * (float)W) / 4.f;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(idx % W), y = (int)((idx / W) % H);
+        const int n = (int)(idx / HW);  // fi*B + b
+        const int fi = n / B, b = n - fi * B;
+        const unsigned char want = (unsigned char)(2 + fi);
+        const unsigned char* sl = sel + (size_t)b * HW;
+        // padded-domain positions that reflect onto (y,x)
+        int py[3], px[3], npy = 0, npx = 0;
+        py[npy++] = y + 1; px[npx++] = x + 1;
+        if (y == 1) py[npy++] = 0;
+        if (y == H - 2) py[npy++] = H + 1;
+        if (x == 1) px[npx++] = 0;
+        if (x == W - 2) px[npx++] = W + 1;
+        float sa[3] = {0.f, 0.f, 0.f}, sb[3] = {0.f, 0.f, 0.f}, sc[3] = {0.f, 0.f, 0.f};
+        for (int iy = 0; iy < npy; ++iy)
+            for (int ix = 0; ix < npx; ++ix) {
+                const int qy0 = max(0, py[iy] - 2), qy1 = min(H - 1, py[iy]);
+                const int qx0 = max(0, px[ix] - 2), qx1 = min(W - 1, px[ix]);
+                for (int qy = qy0; qy <= qy1; ++qy)
+                    for (int qx = qx0; qx <= qx1; ++qx) {
+                        if (sl[qy * W + qx] != want) continue;
+                        const float* co = coef + (size_t)n * 9 * HW + (size_t)qy * W + qx;
+                        for (int c = 0; c < 3; ++c) {
+                            sa[c] += co[(c * 3 + 0) * HW];
+                            sb[c] += co[(c * 3 + 1) * HW];
+                            sc[c] += co[(c * 3 + 2) * HW];
+                        }
+                    }
+            }
+        const float wq = sample_w[b] * scale_all;
+        const bool own = sl[y * W + x] == want;
+        for (int c = 0; c < 3; ++c) {
+            const float xv = pred[((size_t)n * 3 + c) * HW + (size_t)y * W + x];
+            const float yv = target[((size_t)b * 3 + c) * HW + (size_t)y * W + x];
+            float g = sa[c] + sb[c] * xv + sc[c] * yv;
+            if (own) g += (0.15f / 3.f) * (xv > yv ? 1.f : (xv < yv ? -1.f : 0.f));
+            dpred[((size_t)n * 3 + c) * HW + (size_t)y * W + x] = g * wq;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// dz[b,i,j] = sigmoid'(disp) * ( bilinear-upsample^T(ddisp_up)[b,i,j] + smoothness gradient )
+__global__ __launch_bounds__(256) void disp_grad_kernel(const float* __restrict__ ddisp_up, const float* __restrict__ disp,
+                                                        const float* __restrict__ smooth_aux, int n_smooth,
+                                                        float* __restrict__ dz, int B, int h, int w, int H, int W) {
+    const size_t total = (size_t)B * h * w;
+    const int f = H / h;
+    const float ry = (float)h / (float)H, rx = (float)w / (float)W;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int j = (int)(idx % w), i = (int)((idx / w) % h), b = (int)(idx / ((size_t)w * h));
+        float g = 0.f;
+        const int Y0 = max(0, f * i - f), Y1 = min(H, f * i + 2 * f);
+        const int X0 = max(0, f * j - f), X1 = min(W, f * j + 2 * f);
+        for (int Y = Y0; Y < Y1; ++Y) {
+            float sy = ry * ((float)Y + 0.5f) - 0.5f; if (sy < 0.f) sy = 0.f;
+            const int y0 = (int)sy, y1 = y0 + (y0 < h - 1 ? 1 : 0);
+            const float ly = sy - (float)y0;
+            float wy = 0.f;
+            if (y0 == i) wy += 1.f - ly;
+            if (y1 == i) wy += ly;
+            if (wy == 0.f) continue;
+            for (int X = X0; X < X1; ++X) {
+                float sx = rx * ((float)X + 0.5f) - 0.5f; if (sx < 0.f) sx = 0.f;
+                const int x0 = (int)sx, x1 = x0 + (x0 < w - 1 ? 1 : 0);
+                const float lx = sx - (float)x0;
+                float wx = 0.f;
+                if (x0 == j) wx += 1.f - lx;
+                if (x1 == j) wx += lx;
+                if (wx != 0.f) g += wy * wx * ddisp_up[((size_t)b * H + Y) * W + X];
+            }
+        }
+        if (n_smooth > 0 && b == 0) {
+            const float inv0 = smooth_aux[0], fb = smooth_aux[1];
+            const float* gxs = smooth_aux + 2;
+            const float* gys = smooth_aux + 2 + n_smooth;
+            float D = 0.f;
+            if (i == 0) {
+                if (j < n_smooth) D += gxs[j] + gys[j];
+                if (j >= 1 && j - 1 < n_smooth) D -= gxs[j - 1];
+            } else if (i == 1) {
+                if (j < n_smooth) D -= gys[j];
+            }
+            g += inv0 * D - fb;
+        }
+        const float d = disp[idx];
+        dz[idx] = g * d * (1.f - d);
+    }
+}
+
+}  // namespace clslam
+
+using namespace clslam;
+
+static unsigned grid1d(size_t total) { return (unsigned)std::min<size_t>(8192, (total + 255) / 256); }
+
+extern "C" int clslam_photo_map(const float* pred, const float* target, float* map, float* coef, int npred, int batch, int H,
+                                int W, void* stream) {
+    CLSLAM_REQUIRE(pred && target && map && batch > 0 && npred % batch == 0, "photo_map: bad args");
+    CLSLAM_REQUIRE(H >= 2 && W >= 2, "photo_map: image too small for reflection padding");
+    const size_t total = (size_t)npred * H * W;
+    hipLaunchKernelGGL(photo_map_kernel, dim3(grid1d(total)), dim3(256), 0, (hipStream_t)stream, pred, target, map, coef, npred,
+                       batch, H, W);
+    return check_launch("photo_map");
+}
+
+extern "C" int clslam_automask_blocks(int H, int W) { return std::max(1, std::min(128, cdiv(H * W, 2048))); }
+
+extern "C" int clslam_automask(const float* idmap, const float* noise, const float* rpmap, unsigned char* sel, float* partial,
+                               int batch, int H, int W, void* stream) {
+    CLSLAM_REQUIRE(idmap && rpmap && sel && partial, "automask: null");
+    if (!batch) return CLSLAM_OK;
+    const int nblk = clslam_automask_blocks(H, W);
+    hipLaunchKernelGGL(automask_kernel, dim3(nblk, batch), dim3(256), 0, (hipStream_t)stream, idmap, noise, rpmap, sel, partial,
+                       batch, H * W, cdiv(H * W, nblk));
+    return check_launch("automask");
+}
+
+extern "C" int clslam_disp_mean(const float* disp, float* means, int batch, int hw, void* stream) {
+    CLSLAM_REQUIRE(disp && means, "disp_mean: null");
+    if (!batch) return CLSLAM_OK;
+    hipLaunchKernelGGL(disp_mean_kernel, dim3(batch), dim3(256), 0, (hipStream_t)stream, disp, means, hw);
+    return check_launch("disp_mean");
+}
+
+extern "C" int clslam_loss_finalize(const clslam_loss_desc* d, void* stream) {
+    CLSLAM_REQUIRE(d && d->losses && d->pose && d->sample_w, "loss_finalize: null");
+    CLSLAM_REQUIRE(d->n_smooth == 0 || (d->smooth_w && d->smooth_aux), "loss_finalize: smooth buffers missing");
+    FinalizeArgs a;
+    for (int s = 0; s < 4; ++s) { a.partial[s] = d->partial[s]; a.disp[s] = d->disp[s]; a.rgb0[s] = d->rgb0[s]; a.means[s] = d->means[s]; }
+    a.pose = d->pose; a.dist0 = d->dist0; a.dist1 = d->dist1; a.sample_w = d->sample_w; a.smooth_w = d->smooth_w;
+    a.losses = d->losses; a.smooth_aux = d->smooth_aux; a.B = d->batch; a.nblk = d->nblk; a.H = d->H; a.W = d->W;
+    a.n_smooth = d->n_smooth; a.smooth_scale = d->smooth_scale; a.vel_scale = d->vel_scale;
+    CLSLAM_REQUIRE(d->batch <= FIN_MAXB && d->n_smooth <= FIN_MAXB, "loss_finalize: batch > %d", FIN_MAXB);
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
+    return check_launch("loss_finalize");
+}
+
+extern "C" int clslam_photo_grad(const unsigned char* sel, const float* coef, const float* pred, const float* target,
+                                 const float* sample_w, float* dpred, int batch, int H, int W, void* stream) {
+    CLSLAM_REQUIRE(sel && coef && pred && target && sample_w && dpred, "photo_grad: null");
+    const size_t total = (size_t)2 * batch * H * W;
+    if (!total) return CLSLAM_OK;
+    hipLaunchKernelGGL(photo_grad_kernel, dim3(grid1d(total)), dim3(256), 0, (hipStream_t)stream, sel, coef, pred, target,
+                       sample_w, dpred, batch, H, W);
+    return check_launch("photo_grad");
+}
+
+extern "C" int clslam_disp_grad(const float* ddisp_up, const float* disp, const float* smooth_aux, int n_smooth, float* dz,
+                                int batch, int h, int w, int H, int W, void* stream) {
+    CLSLAM_REQUIRE(ddisp_up && disp && dz && H % h == 0 && W % w == 0 && H / h == W / w, "disp_grad: bad args");
+    CLSLAM_REQUIRE(n_smooth == 0 || (smooth_aux && n_smooth < w - 1 && h >= 2), "disp_grad: smoothness layout unsupported");
+    const size_t total = (size_t)batch * h * w;
+    if (!total) return CLSLAM_OK;
+    hipLaunchKernelGGL(disp_grad_kernel, dim3(grid1d(total)), dim3(256), 0, (hipStream_t)stream, ddisp_up, disp, smooth_aux,
+                       n_smooth, dz, batch, h, w, H, W);
+    return check_launch("disp_grad");
+}

@@ -127,6 +127,67 @@ int clslam_pose_head_fwd(const float* x, const float* w2, const float* b2, float
 int clslam_pose_head_bwd(const float* dpose, const float* x, const float* w2, const float* mean, float* dz1,
                          float* dw2, float* db2, int n, int hw, float grad_scale, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Pose -> matrices, view synthesis (forward and backward).  Replaces
+ * depth_pose_prediction/utils.py:34-117 (transformation_from_parameters, invert for frame -1),
+ * networks/layers.py:51-104 (BackprojectDepth, Project3D), utils.py:120-142 (disp_to_depth),
+ * dpp.py:986-1017 (F.interpolate bilinear + F.grid_sample border/align_corners=True) and autograd.
+ * pose (2B,12): row fi*B+b = pose-decoder output of frame idx fi (0: frame -1, 1: frame +1);
+ * cam_t_cam (2,B,4,4); proj (2,B,3,4) = (K*T)[:3]; images planar (B,3,H,W); depth (B,H,W);
+ * warped / dpred (2,B,3,H,W).  min_depth/max_depth <= 0 stand for None.                          */
+int clslam_pose_to_proj(const float* pose, const float* kmat, float* cam_t_cam, float* proj, int batch, void* stream);
+int clslam_warp_fwd(const float* disp_s, int h, int w, const float* src_m1, const float* src_p1, const float* inv_k,
+                    const float* proj, float* depth, float* warped, int batch, int H, int W, float min_depth,
+                    float max_depth, void* stream);
+int clslam_warp_bwd_blocks(int H, int W);
+/* ddisp_up (B,H,W) = dL/d(upsampled disparity); dp_partial [B][nblk][24] block sums of dL/dproj */
+int clslam_warp_bwd(const float* dpred, const float* disp_s, int h, int w, const float* src_m1, const float* src_p1,
+                    const float* inv_k, const float* proj, float* ddisp_up, float* dp_partial, int batch, int H, int W,
+                    float min_depth, float max_depth, void* stream);
+/* dp_partial [nscale][B][nblk][24]; dpose (2B,12) = dL/d(pose-decoder output) incl. the velocity
+ * term (dpp.py:1125-1146; dist0/dist1 = relative_distance(0|1) as float64, sample_w (B)).        */
+int clslam_pose_bwd(const float* dp_partial, int nscale, int nblk, const float* pose, const float* kmat,
+                    const double* dist0, const double* dist1, const float* sample_w, float vel_scale, float* dpose,
+                    int batch, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Photometric / smoothness / velocity loss and its backward.  Replaces networks/layers.py:107-137
+ * (SSIM), dpp.py:1019-1192 (_compute_loss, _compute_smooth_loss incl. its flattening behaviour,
+ * _compute_velocity_loss, _compute_reprojection_loss) and autograd.                               */
+/* map[n] = 0.85*mean_c SSIM + 0.15*mean_c L1 of pred image n (npred x (3,H,W)) vs target n % B;
+ * coef (npred,9,H,W) or NULL: SSIM derivative coefficients kept for clslam_photo_grad.           */
+int clslam_photo_map(const float* pred, const float* target, float* map, float* coef, int npred, int batch, int H,
+                     int W, void* stream);
+int clslam_automask_blocks(int H, int W);
+/* idmap/rpmap (2,B,H,W); noise (B,2,H,W) or NULL; sel (B,H,W) u8 argmin of
+ * [id(-1)+noise, id(+1)+noise, reproj(-1), reproj(+1)]; partial [B][nblk] sums of the minimum.  */
+int clslam_automask(const float* idmap, const float* noise, const float* rpmap, unsigned char* sel, float* partial,
+                    int batch, int H, int W, void* stream);
+int clslam_disp_mean(const float* disp, float* means, int batch, int hw, void* stream);
+typedef struct clslam_loss_desc {
+    const float* partial[4];  /* automask partials per scale [B][nblk]                             */
+    const float* disp[4];     /* ('disp',s) (B,H>>s,W>>s)                                          */
+    const float* rgb0[4];     /* ('rgb',0,s) (B,3,H>>s,W>>s)                                       */
+    const float* means[4];    /* clslam_disp_mean outputs (B)                                      */
+    const float* pose;        /* (2B,12)                                                           */
+    const double* dist0;      /* ('relative_distance',0) (B) float64                               */
+    const double* dist1;
+    const float* sample_w;    /* (B) loss weights of the local samples (dpp.py:1031-1032)          */
+    const float* smooth_w;    /* (n_smooth) weights of the smoothness terms                        */
+    float* losses;            /* [18]: 4 x {reprojection, smooth, reg, depth_loss/scale}, velocity, total */
+    float* smooth_aux;        /* [4][2+2*n_smooth] kept for clslam_disp_grad                        */
+    int32_t batch, nblk, H, W, n_smooth;
+    float smooth_scale, vel_scale;
+} clslam_loss_desc;
+int clslam_loss_finalize(const clslam_loss_desc* desc, void* stream);
+/* dpred (2,B,3,H,W) = dL/d(warped images) of one scale.                                          */
+int clslam_photo_grad(const unsigned char* sel, const float* coef, const float* pred, const float* target,
+                      const float* sample_w, float* dpred, int batch, int H, int W, void* stream);
+/* dz (B,h,w) = dL/d(pre-sigmoid disparity logits): transposed bilinear upsample of ddisp_up plus the
+ * smoothness gradient (smooth_aux slice of this scale), times sigmoid'.                           */
+int clslam_disp_grad(const float* ddisp_up, const float* disp, const float* smooth_aux, int n_smooth, float* dz,
+                     int batch, int h, int w, int H, int W, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
