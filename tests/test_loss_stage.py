@@ -128,15 +128,30 @@ def test_loss_stage_matches_oracle(backend, B, H, W, max_depth, aligned):
     # gradients: fraction of pixels choosing a reprojection must be non-trivial for the test to bite
     frac = float((got['sel'].cpu() >= 2).float().mean())
     assert frac > (0.2 if aligned else 0.002), frac
+    # A near-tie in the 4-way min can resolve differently at fp32 round-off (the warp itself is
+    # ~1e-6 away from torch's normalise->grid_sample->unnormalise round trip).  Such a pixel changes
+    # the gradient of its 3x3 neighbourhood and of the pose.  Detect it against the oracle's argmin,
+    # require it to be a genuine near-tie, and only then loosen the gradient tolerance.
+    flipped = {}
     for s in range(4):
-        # A near-tie in the 4-way min (or in sign(pred-target)) can resolve differently at fp32
-        # round-off for an isolated pixel, which changes the gradient of its 3x3 neighbourhood:
-        # allow <= 0.1 % outlier pixels, everything else must agree to 2e-4 of the max gradient.
+        rp = torch.cat([OF.reprojection_loss(outputs['rgb', f, s].detach(), inputs['rgb', 0, 0]) for f in (-1, 1)], 1)
+        idl = torch.cat([OF.reprojection_loss(inputs['rgb', f, 0], inputs['rgb', 0, 0]) for f in (-1, 1)], 1) + noise[s]
+        comb = torch.cat((idl, rp), 1)
+        ours = got['sel'][s].cpu().long()
+        mism = (comb.argmin(1) != ours).nonzero()
+        assert len(mism) <= 3, (s, len(mism))
+        for m in mism:
+            v = comb[m[0], :, m[1], m[2]]
+            assert abs(float(v.min() - v[ours[m[0], m[1], m[2]]])) < 1e-5, v.tolist()
+        flipped[s] = len(mism)
+    any_flip = sum(flipped.values()) > 0
+    for s in range(4):
         zg = z[s].grad.squeeze(1)
         diff = (got['dz'][s].cpu() - zg).abs()
-        outliers = int((diff > 2e-4 * zg.abs().max()).sum())
-        assert outliers <= max(1, zg.numel() // 1000), (s, outliers)
-        assert float(diff.double().norm() / zg.double().norm()) < 5e-3, s
+        if flipped[s] == 0:
+            assert float(diff.max() / zg.abs().max()) < 2e-4, (s, float(diff.max() / zg.abs().max()))
+        else:
+            assert float(diff.double().norm() / zg.double().norm()) < 5e-2, s
     pg = pose.grad
-    assert rel_err(got['dpose'].cpu()[:, :6], pg[:, :6]) < 2e-4, rel_err(got['dpose'].cpu()[:, :6], pg[:, :6])
+    assert rel_err(got['dpose'].cpu()[:, :6], pg[:, :6]) < (2e-2 if any_flip else 2e-4)
     assert float(got['dpose'].cpu()[:, 6:].abs().max()) == 0.0
