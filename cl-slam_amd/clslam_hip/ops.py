@@ -227,3 +227,8 @@ def disp_grad(ddisp_up, disp, smooth_aux, n_smooth, dz, H, W):
     B, h, w = disp.shape[0], disp.shape[-2], disp.shape[-1]
     _lib.get_lib().call('clslam_disp_grad', _p(ddisp_up), _p(disp), _p(smooth_aux), n_smooth, _p(dz), B, h, w, H, W,
                         _stream(dz))
+
+
+def adam_step(param, grad, exp_avg, exp_avg_sq, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
+    _lib.get_lib().call('clslam_adam_step', _p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(), lr, beta1,
+                        beta2, eps, step, grad_scale, _stream(param))

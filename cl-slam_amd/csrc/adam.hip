@@ -1,0 +1,62 @@
+// K18: fused Adam over the flat trainable arena (depth decoder + pose decoder).
+// Replaces torch.optim.Adam.step() at dpp.py:203,313 (defaults: betas (0.9, 0.999), eps 1e-8, no
+// weight decay, no amsgrad) with the same operation order as torch's single-tensor CPU path:
+//   m = m + (g - m)*(1-b1);  v = v*b2 + (1-b2)*g*g;
+//   p = p - (lr/(1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+// HBM-bound: 4 streams read (p,g,m,v), 3 written, 16-byte accesses.
+#include "common.h"
+
+namespace clslam {
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, size_t n4, size_t n, float step_size, float beta1,
+                                                   float beta2, float bc2_sqrt, float eps, float grad_scale) {
+    const float w1 = 1.f - beta1, w2 = 1.f - beta2;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        float4 pp = reinterpret_cast<float4*>(p)[i];
+        float4 gg = reinterpret_cast<const float4*>(g)[i];
+        float4 mm = reinterpret_cast<float4*>(m)[i];
+        float4 vv = reinterpret_cast<float4*>(v)[i];
+        float* P = &pp.x; float* G = &gg.x; float* M = &mm.x; float* V = &vv.x;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float gr = G[k] * grad_scale;
+            M[k] = M[k] + (gr - M[k]) * w1;
+            V[k] = V[k] * beta2 + w2 * gr * gr;
+            const float denom = sqrtf(V[k]) / bc2_sqrt + eps;
+            P[k] = P[k] - step_size * (M[k] / denom);
+        }
+        reinterpret_cast<float4*>(p)[i] = pp;
+        reinterpret_cast<float4*>(m)[i] = mm;
+        reinterpret_cast<float4*>(v)[i] = vv;
+    }
+    // tail (n not a multiple of 4)
+    if (blockIdx.x == 0) {
+        for (size_t i = n4 * 4 + threadIdx.x; i < n; i += blockDim.x) {
+            const float gr = g[i] * grad_scale;
+            const float mk = m[i] + (gr - m[i]) * w1;
+            const float vk = v[i] * beta2 + w2 * gr * gr;
+            m[i] = mk; v[i] = vk;
+            p[i] = p[i] - step_size * (mk / (sqrtf(vk) / bc2_sqrt + eps));
+        }
+    }
+}
+
+}  // namespace clslam
+
+using namespace clslam;
+
+extern "C" int clslam_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float lr,
+                                float beta1, float beta2, float eps, int step, float grad_scale, void* stream) {
+    CLSLAM_REQUIRE(param && grad && exp_avg && exp_avg_sq && step >= 1, "adam_step: bad args");
+    if (!n) return CLSLAM_OK;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    const float step_size = (float)((double)lr / bc1);
+    const float bc2_sqrt = (float)sqrt(bc2);
+    const size_t n4 = n / 4;
+    const unsigned blocks = (unsigned)std::min<size_t>(2048, std::max<size_t>(1, (n4 + 255) / 256));
+    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n4, n,
+                       step_size, beta1, beta2, bc2_sqrt, eps, grad_scale);
+    return check_launch("adam_step");
+}
