@@ -68,7 +68,7 @@ _SIGNATURES = {
     'clslam_disp_mean': [fptr, fptr, i32, i32, C.c_void_p],
     'clslam_loss_finalize': [C.POINTER(LossDesc), C.c_void_p],
     'clslam_photo_grad': [fptr, fptr, fptr, fptr, fptr, fptr, i32, i32, i32, C.c_void_p],
-    'clslam_adam_step': [fptr, fptr, fptr, fptr, C.c_size_t, C.c_float, C.c_float, C.c_float, C.c_float, i32, C.c_float,
+    'clslam_adam_step': [fptr, fptr, fptr, fptr, C.c_size_t, C.c_double, C.c_double, C.c_double, C.c_double, i32, C.c_float,
                          C.c_void_p],
     'clslam_disp_grad': [fptr, fptr, fptr, i32, fptr, i32, i32, i32, i32, i32, C.c_void_p],
 }

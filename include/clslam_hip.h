@@ -192,8 +192,8 @@ int clslam_disp_grad(const float* ddisp_up, const float* disp, const float* smoo
  * Fused Adam over a flat fp32 arena.  Replaces torch.optim.Adam.step() (dpp.py:203,313; torch
  * defaults, same op order as the single-tensor CPU implementation).  grad is multiplied by
  * grad_scale first (1 for single GPU; data-parallel ranks all-reduce with SUM, so it stays 1).  */
-int clslam_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float lr,
-                     float beta1, float beta2, float eps, int step, float grad_scale, void* stream);
+int clslam_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, double lr,
+                     double beta1, double beta2, double eps, int step, float grad_scale, void* stream);
 
 #ifdef __cplusplus
 }
