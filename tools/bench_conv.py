@@ -1,0 +1,76 @@
+#!/usr/bin/env python
+"""Micro-benchmark of clslam_conv2d / clslam_conv_wgrad on the real layer shapes (192x640, B=5).
+Prints achieved TFLOP/s per layer and tile configuration (fp32 MFMA peak = 157.3)."""
+import sys
+from pathlib import Path
+
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1] / 'cl-slam_amd'))
+from clslam_hip import ops  # noqa: E402
+
+dev = torch.device('cuda:0')
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+H, W = 192, 640
+# name, B mult, Hi, Wi, Ca, Cb, Cout, k, stride, reflect, ups
+LAYERS = [
+    ('layer1 64->64 @48x160', 1, 48, 160, 64, 0, 64, 3, 1, 0, 0),
+    ('layer2 128->128 @24x80', 1, 24, 80, 128, 0, 128, 3, 1, 0, 0),
+    ('layer3 256->256 @12x40', 1, 12, 40, 256, 0, 256, 3, 1, 0, 0),
+    ('layer4 512->512 @6x20', 1, 6, 20, 512, 0, 512, 3, 1, 0, 0),
+    ('layer4 pose 2B', 2, 6, 20, 512, 0, 512, 3, 1, 0, 0),
+    ('layer2.0 64->128 s2', 1, 48, 160, 64, 0, 128, 3, 2, 0, 0),
+    ('upconv_4_1 512->256 @12x40', 1, 12, 40, 256, 256, 256, 3, 1, 1, 1),
+    ('upconv_3_1 256->128 @24x80', 1, 24, 80, 128, 128, 128, 3, 1, 1, 1),
+    ('upconv_2_1 128->64 @48x160', 1, 48, 160, 64, 64, 64, 3, 1, 1, 1),
+    ('upconv_1_1 96->32 @96x320', 1, 96, 320, 32, 64, 32, 3, 1, 1, 1),
+    ('upconv_0_0 32->16 @96x320', 1, 96, 320, 32, 0, 16, 3, 1, 1, 0),
+    ('upconv_0_1 16->16 @192x640', 1, 192, 640, 16, 0, 16, 3, 1, 1, 1),
+]
+
+
+def timeit(fn, iters=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e-3
+
+
+for name, bm, Hi, Wi, Ca, Cb, Cout, k, stride, refl, ups in LAYERS:
+    Bn = B * bm
+    Ha, Wa = (Hi // 2, Wi // 2) if ups else (Hi, Wi)
+    xa = torch.randn(Bn, Ha, Wa, Ca, device=dev)
+    xb = torch.randn(Bn, Hi, Wi, Cb, device=dev) if Cb else None
+    w = torch.randn(Cout, k * k, Ca + Cb, device=dev) * 0.05
+    Ho, Wo = (Hi - 1) // stride + 1, (Wi - 1) // stride + 1
+    out = torch.empty(Bn, Ho, Wo, Cout, device=dev)
+    flops = 2.0 * Bn * Ho * Wo * Cout * k * k * (Ca + Cb)
+    line = f'{name:32s} M={Bn*Ho*Wo:7d} {flops/1e9:7.2f} GF |'
+    cfgs = [-1, 0, 1, 2, 3, 4, 5, 6]
+    for cfg in cfgs:
+        try:
+            t = timeit(lambda: ops.conv2d(xa, w, out, src_b=xb, ksize=k, stride=stride, pad_mode=refl, upsample_a=bool(ups),
+                                          act=1, config=cfg))
+            line += f' c{cfg}:{flops/t/1e12:6.1f}'
+        except Exception:
+            line += f' c{cfg}:   -  '
+    # wgrad
+    dz = torch.randn(Bn, Ho, Wo, Cout, device=dev)
+    desc = ops.conv_desc(xa, (Bn, Ho, Wo, Cout), src_b=xb, ksize=k, stride=stride, pad_mode=refl, upsample_a=bool(ups))
+    for target in (512, 2048):
+        splits = ops.wgrad_splits(desc, target)
+        part = torch.empty(splits * w.numel(), device=dev)
+        dw = torch.empty(w.numel(), device=dev)
+
+        def f():
+            ops.conv_wgrad(desc, dz, part, splits)
+            ops.reduce_partials(part, dw, w.numel(), splits)
+        t = timeit(f)
+        line += f' | wg{target}(s{splits}):{flops/t/1e12:6.1f}'
+    print(line, flush=True)
