@@ -1,0 +1,580 @@
+"""The per-frame schedule of the MI355X-native depth/pose path.
+
+One ``Engine`` owns, in HBM:
+  * the frozen encoder weights, re-laid out once per ``load`` (OHWI conv weights, eval-mode
+    BatchNorm folded into per-channel scale/shift -- legal because adaptation never changes encoder
+    or BN parameters, dpp.py:308,813-819),
+  * ONE flat fp32 arena for the 36 trainable tensors (depth decoder + pose decoder, 4.47 M floats)
+    and three more of the same layout for gradients and Adam's two moments -- so the data-parallel
+    gradient exchange is a single all-reduce and Adam a single kernel,
+  * a workspace of NHWC activations and loss-stage planes, planned once per batch size (every shape
+    is static given B, H, W).
+and sequences the C-ABI kernels (clslam_hip.ops) for: encoder/decoder/pose forward -> view synthesis
++ loss -> hand-written backward of everything that has gradients -> fused Adam.  No torch autograd,
+no torch.nn compute: torch supplies device memory, streams and torch.distributed only.
+
+Reference call graph being replaced: dpp.py:906-923 (_process_batch), :925-974, :976-1017,
+:1019-1120, and dpp.py:309-313 (zero_grad / backward / optimizer.step).
+"""
+import math
+from types import SimpleNamespace
+from typing import Any, Dict, List, Optional, Tuple
+
+import torch
+
+from . import ops
+from ._lib import ACT_ELU, ACT_NONE, ACT_RELU, PAD_REFLECT, PAD_ZERO, ClslamError, get_lib
+
+NUM_CH_ENC = (64, 64, 128, 256, 512)
+NUM_CH_DEC = (16, 32, 64, 128, 256)
+BN_EPS = 1e-5
+
+LOSS_NAMES = ('reprojection_loss', 'smooth_loss', 'reg_loss', 'depth_loss')
+
+
+def _align4(n: int) -> int:
+    return (n + 3) // 4 * 4
+
+
+class TrainableLayout:
+    """Flat arena layout of the trainable tensors in compute order; names are
+    '<model>/<state-dict key>' in the reference's parameter order."""
+
+    def __init__(self) -> None:
+        self.entries: List[Tuple[str, int, Tuple[int, ...]]] = []  # (name, offset, reference shape)
+        self.offset: Dict[str, int] = {}
+        off = 0
+
+        def add(name: str, shape: Tuple[int, ...]) -> None:
+            nonlocal off
+            self.entries.append((name, off, shape))
+            self.offset[name] = off
+            off = _align4(off + math.prod(shape))
+
+        for i in range(4, -1, -1):
+            cin0 = NUM_CH_ENC[-1] if i == 4 else NUM_CH_DEC[i + 1]
+            add(f'depth_decoder/upconv_{i}_0.conv.conv.weight', (NUM_CH_DEC[i], cin0, 3, 3))
+            add(f'depth_decoder/upconv_{i}_0.conv.conv.bias', (NUM_CH_DEC[i],))
+            cin1 = NUM_CH_DEC[i] + (NUM_CH_ENC[i - 1] if i > 0 else 0)
+            add(f'depth_decoder/upconv_{i}_1.conv.conv.weight', (NUM_CH_DEC[i], cin1, 3, 3))
+            add(f'depth_decoder/upconv_{i}_1.conv.conv.bias', (NUM_CH_DEC[i],))
+        for s in range(4):
+            # weight immediately followed by its bias (clslam_dispconv_wgrad reduces both at once)
+            name = f'depth_decoder/dispconv_{s}.conv.weight'
+            self.entries.append((name, off, (1, NUM_CH_DEC[s], 3, 3)))
+            self.offset[name] = off
+            off += 9 * NUM_CH_DEC[s]
+            name = f'depth_decoder/dispconv_{s}.conv.bias'
+            self.entries.append((name, off, (1,)))
+            self.offset[name] = off
+            off = _align4(off + 1)
+        add('pose_decoder/squeeze.weight', (256, 512, 1, 1))
+        add('pose_decoder/squeeze.bias', (256,))
+        for k in (0, 1):
+            add(f'pose_decoder/pose_{k}.weight', (256, 256, 3, 3))
+            add(f'pose_decoder/pose_{k}.bias', (256,))
+        add('pose_decoder/pose_2.weight', (12, 256, 1, 1))
+        add('pose_decoder/pose_2.bias', (12,))
+        self.size = off
+
+    @staticmethod
+    def to_compute(t: torch.Tensor) -> torch.Tensor:
+        """reference OIHW -> OHWI ([Cout][taps][Cin]); 1-D tensors unchanged."""
+        return t.permute(0, 2, 3, 1).reshape(-1) if t.dim() == 4 else t.reshape(-1)
+
+    @staticmethod
+    def to_reference(flat: torch.Tensor, shape: Tuple[int, ...]) -> torch.Tensor:
+        if len(shape) == 4:
+            o, i, kh, kw = shape
+            return flat.view(o, kh, kw, i).permute(0, 3, 1, 2)
+        return flat.view(shape)
+
+
+class Engine:
+    def __init__(self, height: int, width: int, device: torch.device, *, min_depth: Optional[float],
+                 max_depth: Optional[float], disparity_smoothness: float, velocity_loss_scaling: Optional[float],
+                 reference_quirks: bool = True) -> None:
+        lib = get_lib()  # raises if libclslam_hip.so is missing -- there is no fallback
+        if device.type != lib.device_type:
+            raise ClslamError(f'engine on {device} but {lib.path.name} executes on {lib.device_type}; the MI355X path '
+                              'needs a GPU and has no CPU fallback')
+        if height % 32 or width % 32:
+            raise ValueError('height and width must be multiples of 32 (five stride-2 stages)')
+        if not reference_quirks:
+            raise NotImplementedError('only the reference smoothness behaviour (SURVEY.md 0.3) is implemented')
+        self.H, self.W, self.device = height, width, device
+        self.min_depth, self.max_depth = min_depth, max_depth
+        self.smooth_scale = float(disparity_smoothness)
+        self.vel_scale = float(velocity_loss_scaling) if velocity_loss_scaling else 0.0
+        self.layout = TrainableLayout()
+        n = self.layout.size
+        self.w = torch.zeros(n, device=device)
+        self.g = torch.zeros(n, device=device)
+        self.m = torch.zeros(n, device=device)
+        self.v = torch.zeros(n, device=device)
+        self.adam_step_count = 0
+        self.enc: Dict[str, Any] = {}
+        self._ws: Dict[int, SimpleNamespace] = {}
+        self.models = None
+        self._packed_version = None
+        self._modules_stale = False
+        self.dist = None  # (process_group-like) set by enable_data_parallel
+
+    # ------------------------------------------------------------------------------------------
+    # parameters
+    def bind(self, models: Dict[str, torch.nn.Module]) -> None:
+        self.models = models
+        for name, m in models.items():
+            m._bind(self, name)
+
+    def _module_version(self) -> int:
+        v = 0
+        for m in self.models.values():
+            for t in torch.nn.Module.state_dict(m, keep_vars=True).values():
+                v += t._version
+        return v
+
+    def pack_if_needed(self) -> None:
+        """Re-layout the module parameters into the engine's buffers when they were modified from
+        outside (load_model, load_state_dict, manual edits)."""
+        ver = self._module_version()
+        if ver != self._packed_version:
+            if self._modules_stale:
+                raise ClslamError('module parameters were modified while newer adapted weights live in the engine; '
+                                  'call sync_modules() first')
+            self.pack()
+
+    @torch.no_grad()
+    def pack(self) -> None:
+        dev = self.device
+        for which in ('depth_encoder', 'pose_encoder'):
+            sd = {k: v.detach().to(dev, torch.float32) for k, v in torch.nn.Module.state_dict(self.models[which]).items()}
+            e = SimpleNamespace()
+
+            def bn(prefix):
+                scale = sd[prefix + '.weight'] / torch.sqrt(sd[prefix + '.running_var'] + BN_EPS)
+                shift = sd[prefix + '.bias'] - sd[prefix + '.running_mean'] * scale
+                return scale.contiguous(), shift.contiguous()
+
+            def conv(key):
+                wt = sd[key]
+                return wt.permute(0, 2, 3, 1).reshape(wt.shape[0], wt.shape[2] * wt.shape[3], wt.shape[1]).contiguous()
+
+            e.stem_w = sd['resnet.conv1.weight'].contiguous()
+            e.stem_scale, e.stem_shift = bn('resnet.bn1')
+            e.blocks = []
+            for li, (cin, cout, stride) in enumerate(((64, 64, 1), (64, 128, 2), (128, 256, 2), (256, 512, 2)), start=1):
+                for bi in range(2):
+                    p = f'resnet.layer{li}.{bi}'
+                    blk = SimpleNamespace(stride=stride if bi == 0 else 1, cin=cin if bi == 0 else cout, cout=cout)
+                    blk.w1 = conv(p + '.conv1.weight'); blk.s1, blk.b1 = bn(p + '.bn1')
+                    blk.w2 = conv(p + '.conv2.weight'); blk.s2, blk.b2 = bn(p + '.bn2')
+                    blk.wd = None
+                    if (p + '.downsample.0.weight') in sd:
+                        blk.wd = conv(p + '.downsample.0.weight'); blk.sd, blk.bd = bn(p + '.downsample.1')
+                    e.blocks.append(blk)
+            self.enc[which] = e
+        for name, off, shape in self.layout.entries:
+            model, key = name.split('/', 1)
+            t = torch.nn.Module.state_dict(self.models[model])[key].detach().to(dev, torch.float32)
+            flat = TrainableLayout.to_compute(t)
+            self.w[off:off + flat.numel()].copy_(flat)
+        self._packed_version = self._module_version()
+        self._modules_stale = False
+
+    @torch.no_grad()
+    def sync_modules(self) -> None:
+        """Write the engine's adapted weights back into the module parameters (reference layout)."""
+        if not self._modules_stale or self.models is None:
+            return
+        for name, off, shape in self.layout.entries:
+            model, key = name.split('/', 1)
+            p = torch.nn.Module.state_dict(self.models[model], keep_vars=True)[key]
+            p.data.copy_(TrainableLayout.to_reference(self.w[off:off + math.prod(shape)], shape))
+        self._modules_stale = False
+        self._packed_version = self._module_version()
+
+    def wview(self, name: str) -> torch.Tensor:
+        for n, off, shape in self.layout.entries:
+            if n == name:
+                return self.w[off:off + math.prod(shape)]
+        raise KeyError(name)
+
+    def _slot(self, buf: torch.Tensor, name: str, numel: int) -> torch.Tensor:
+        off = self.layout.offset[name]
+        return buf[off:off + numel]
+
+    # ------------------------------------------------------------------------------------------
+    # workspace
+    def workspace(self, B: int) -> SimpleNamespace:
+        ws = self._ws.get(B)
+        if ws is not None:
+            return ws
+        dev, H, W = self.device, self.H, self.W
+        E = lambda *s: torch.empty(*s, device=dev)  # noqa: E731
+        ws = SimpleNamespace(B=B)
+        hs = [H >> k for k in range(6)]
+        wsz = [W >> k for k in range(6)]
+
+        ws.denc = self._enc_bufs(B)
+        ws.penc = self._enc_bufs(2 * B)
+        # depth decoder activations: x[i][j] = output of upconv_i_j (post-ELU), NHWC
+        ws.x = {}
+        for i in range(4, -1, -1):
+            ws.x[i, 0] = E(B, hs[i + 1], wsz[i + 1], NUM_CH_DEC[i])
+            ws.x[i, 1] = E(B, hs[i], wsz[i], NUM_CH_DEC[i])
+        ws.disp = [E(B, hs[s], wsz[s]) for s in range(4)]
+        # pose decoder
+        ws.sq = E(2 * B, hs[5], wsz[5], 256)
+        ws.p0 = E(2 * B, hs[5], wsz[5], 256)
+        ws.p1 = E(2 * B, hs[5], wsz[5], 256)
+        ws.pmean = E(2 * B, 256)
+        ws.pose = E(2 * B, 12)
+        # loss stage
+        ws.T = E(2, B, 4, 4)
+        ws.P = E(2, B, 3, 4)
+        ws.depth = E(4, B, H, W)
+        ws.warped = E(4, 2, B, 3, H, W)
+        ws.idsrc = E(2, B, 3, H, W)
+        ws.idmap = E(2, B, H, W)
+        ws.rpmap = E(4, 2, B, H, W)
+        ws.coef = None  # allocated on the first training step
+        ws.sel = torch.empty(4, B, H, W, dtype=torch.uint8, device=dev)
+        ws.nblk = ops.automask_blocks(H, W)
+        ws.partial = E(4, B, ws.nblk)
+        ws.means = E(4, B)
+        ws.losses = E(18)
+        ws.noise = E(4, B, 2, H, W)
+        ws.train = None
+        self._ws[B] = ws
+        return ws
+
+    def _enc_bufs(self, n: int) -> SimpleNamespace:
+        dev, H, W = self.device, self.H, self.W
+        E = lambda *s: torch.empty(*s, device=dev)  # noqa: E731
+        hs = [H >> k for k in range(6)]
+        wsz = [W >> k for k in range(6)]
+        e = SimpleNamespace()
+        e.f0 = E(n, hs[1], wsz[1], 64)
+        e.pool = E(n, hs[2], wsz[2], 64)
+        e.t = [E(n, hs[2 + li], wsz[2 + li], c) for li, c in enumerate((64, 128, 256, 512))]
+        e.ds = [None] + [E(n, hs[2 + li], wsz[2 + li], c) for li, c in ((1, 128), (2, 256), (3, 512))]
+        e.y = [[E(n, hs[2 + li], wsz[2 + li], c) for _ in range(2)] for li, c in enumerate((64, 128, 256, 512))]
+        return e
+
+    def _train_bufs(self, ws: SimpleNamespace) -> SimpleNamespace:
+        if ws.train is not None:
+            return ws.train
+        dev, H, W, B = self.device, self.H, self.W, ws.B
+        E = lambda *s: torch.empty(*s, device=dev)  # noqa: E731
+        t = SimpleNamespace()
+        ws.coef = E(4, 2, B, 9, H, W)
+        t.dpred = E(2, B, 3, H, W)
+        t.ddisp_up = E(B, H, W)
+        t.nb2 = ops.warp_bwd_blocks(H, W)
+        t.dp_partial = E(4, B, t.nb2, 24)
+        t.dz_disp = [torch.empty_like(d) for d in ws.disp]
+        t.dpose = E(2 * B, 12)
+        t.dz = {k: torch.empty_like(v) for k, v in ws.x.items()}   # d(pre-ELU) of every upconv output
+        pad_elems = max(B * ((H >> i) + 2) * ((W >> i) + 2) * NUM_CH_DEC[i] for i in range(5))
+        t.dxp = [E(pad_elems), E(pad_elems)]
+        t.wt = E(256 * 9 * 256)
+        t.dz_p1 = torch.empty_like(ws.p1)
+        t.dz_p0 = torch.empty_like(ws.p0)
+        t.dz_sq = torch.empty_like(ws.sq)
+        t.partial = None
+        t.partial_elems = 0
+        t.colsum = E(1024 * 256)
+        t.disp_part = E(512 * (9 * 128 + 1))
+        ws.train = t
+        return t
+
+    # ------------------------------------------------------------------------------------------
+    # forward pieces
+    def _encoder(self, e, bufs, n: int, stem_inputs) -> List[torch.Tensor]:
+        """stem_inputs: list of (img_a, img_b|None, batch offset, count); returns the 5 NHWC features."""
+        for img_a, img_b, off, cnt in stem_inputs:
+            ops.stem_conv(img_a, img_b, e.stem_w, e.stem_scale, e.stem_shift, bufs.f0[off:off + cnt])
+        ops.maxpool3x3s2(bufs.f0, bufs.pool)
+        x = bufs.pool
+        feats = [bufs.f0]
+        for li in range(4):
+            for bi in range(2):
+                blk = e.blocks[li * 2 + bi]
+                t, y = bufs.t[li], bufs.y[li][bi]
+                ops.conv2d(x, blk.w1, t, scale=blk.s1, shift=blk.b1, ksize=3, stride=blk.stride, act=ACT_RELU)
+                res = x
+                if blk.wd is not None:
+                    res = bufs.ds[li]
+                    ops.conv2d(x, blk.wd, res, scale=blk.sd, shift=blk.bd, ksize=1, stride=blk.stride, pad=0, act=ACT_NONE)
+                ops.conv2d(t, blk.w2, y, scale=blk.s2, shift=blk.b2, residual=res, ksize=3, act=ACT_RELU)
+                x = y
+            feats.append(x)
+        return feats
+
+    def _wb(self, prefix: str, cout: int, cin: int, taps: int):
+        w = self._slot(self.w, prefix + '.weight', cout * taps * cin).view(cout, taps, cin)
+        b = self._slot(self.w, prefix + '.bias', cout)
+        return w, b
+
+    def _depth_decoder(self, ws, feats: List[torch.Tensor]) -> None:
+        x = feats[4]
+        for i in range(4, -1, -1):
+            cin0 = NUM_CH_ENC[-1] if i == 4 else NUM_CH_DEC[i + 1]
+            w, b = self._wb(f'depth_decoder/upconv_{i}_0.conv.conv', NUM_CH_DEC[i], cin0, 9)
+            ops.conv2d(x, w, ws.x[i, 0], shift=b, ksize=3, pad_mode=PAD_REFLECT, act=ACT_ELU)
+            skip = feats[i - 1] if i > 0 else None
+            cin1 = NUM_CH_DEC[i] + (NUM_CH_ENC[i - 1] if i > 0 else 0)
+            w, b = self._wb(f'depth_decoder/upconv_{i}_1.conv.conv', NUM_CH_DEC[i], cin1, 9)
+            ops.conv2d(ws.x[i, 0], w, ws.x[i, 1], src_b=skip, shift=b, ksize=3, pad_mode=PAD_REFLECT, upsample_a=True,
+                       act=ACT_ELU)
+            x = ws.x[i, 1]
+            if i <= 3:
+                w, b = self._wb(f'depth_decoder/dispconv_{i}.conv', 1, NUM_CH_DEC[i], 9)
+                ops.dispconv_fwd(x, w.view(9, NUM_CH_DEC[i]), b, ws.disp[i])
+
+    def _pose_decoder(self, ws, f4: torch.Tensor) -> None:
+        w, b = self._wb('pose_decoder/squeeze', 256, 512, 1)
+        ops.conv2d(f4, w, ws.sq, shift=b, ksize=1, pad=0, act=ACT_RELU)
+        w, b = self._wb('pose_decoder/pose_0', 256, 256, 9)
+        ops.conv2d(ws.sq, w, ws.p0, shift=b, ksize=3, act=ACT_RELU)
+        w, b = self._wb('pose_decoder/pose_1', 256, 256, 9)
+        ops.conv2d(ws.p0, w, ws.p1, shift=b, ksize=3, act=ACT_RELU)
+        w, b = self._wb('pose_decoder/pose_2', 12, 256, 1)
+        ops.pose_head_fwd(ws.p1, w.view(12, 256), b, ws.pmean, ws.pose)
+
+    # ------------------------------------------------------------------------------------------
+    def forward(self, inputs: Dict[Any, torch.Tensor], *, train: bool, sample_w: torch.Tensor,
+                smooth_w: Optional[torch.Tensor], noise: Optional[Dict[int, torch.Tensor]] = None,
+                draw_noise: bool = True) -> Tuple[Dict[Any, torch.Tensor], torch.Tensor]:
+        """One _process_batch (dpp.py:906-923).  `inputs` tensors must already live on the device."""
+        H, W = self.H, self.W
+        aug = {f: self._img(inputs['rgb_aug', f, 0]) for f in (-1, 0, 1)}
+        rgb = {f: self._img(inputs['rgb', f, 0]) for f in (-1, 0, 1)}
+        B = aug[0].shape[0]
+        ws = self.workspace(B)
+        if train:
+            self._train_bufs(ws)
+        # networks ---------------------------------------------------------------------------
+        dfeats = self._encoder(self.enc['depth_encoder'], ws.denc, B, [(aug[0], None, 0, B)])
+        self._depth_decoder(ws, dfeats)
+        # pose pairs in temporal order (dpp.py:949-955): (-1, 0) and (0, +1), batched as 2B
+        pfeats = self._encoder(self.enc['pose_encoder'], ws.penc, 2 * B, [(aug[-1], aug[0], 0, B), (aug[0], aug[1], B, B)])
+        self._pose_decoder(ws, pfeats[4])
+        ws.dfeats, ws.pf4 = dfeats, pfeats[4]
+        # view synthesis + loss ------------------------------------------------------------------
+        K = self._mat(inputs['camera_matrix', 0])
+        Kinv = self._mat(inputs['inv_camera_matrix', 0])
+        ops.pose_to_proj(ws.pose, K, ws.T, ws.P)
+        for s in range(4):
+            ops.warp_fwd(ws.disp[s], rgb[-1], rgb[1], Kinv, ws.P, ws.depth[s], ws.warped[s], self.min_depth, self.max_depth)
+        ws.idsrc[0].copy_(rgb[-1])
+        ws.idsrc[1].copy_(rgb[1])
+        ops.photo_map(ws.idsrc, rgb[0], ws.idmap, None, 2 * B, B, H, W)
+        if noise is not None:
+            for s in range(4):
+                ws.noise[s].copy_(noise[s])
+            have_noise = True
+        elif draw_noise:
+            ws.noise.normal_().mul_(1e-5)  # dpp.py:1055-1056
+            have_noise = True
+        else:
+            have_noise = False
+        for s in range(4):
+            ops.photo_map(ws.warped[s], rgb[0], ws.rpmap[s], ws.coef[s] if train else None, 2 * B, B, H, W)
+            ops.automask(ws.idmap, ws.noise[s] if have_noise else None, ws.rpmap[s], ws.sel[s], ws.partial[s], B, H, W)
+            ops.disp_mean(ws.disp[s], ws.means[s])
+        n_smooth = 0 if smooth_w is None else int(smooth_w.numel())
+        if n_smooth and not (n_smooth < (W >> 3) - 1):
+            raise ClslamError('reference smoothness layout needs batch < width/8 - 1')
+        aux = getattr(ws, 'smooth_aux', None)
+        if n_smooth and (aux is None or aux.shape[1] != 2 + 2 * n_smooth):
+            aux = torch.zeros(4, 2 + 2 * n_smooth, device=self.device)
+            ws.smooth_aux = aux
+        d0 = inputs['relative_distance', 0].to(torch.float64).reshape(-1).contiguous() if self.vel_scale > 0 else None
+        d1 = inputs['relative_distance', 1].to(torch.float64).reshape(-1).contiguous() if self.vel_scale > 0 else None
+        rgb0 = [self._img(inputs['rgb', 0, s]) for s in range(4)]
+        ops.loss_finalize([ws.partial[s] for s in range(4)], ws.disp, rgb0, [ws.means[s] for s in range(4)], ws.pose, d0, d1,
+                          sample_w, smooth_w if n_smooth else None, ws.losses, aux if n_smooth else None, B, ws.nblk, H, W,
+                          n_smooth, self.smooth_scale, self.vel_scale)
+        ws.ctx = SimpleNamespace(rgb=rgb, K=K, Kinv=Kinv, d0=d0, d1=d1, sample_w=sample_w, n_smooth=n_smooth,
+                                 aux=aux if n_smooth else None, B=B)
+        return self._outputs(ws, B), ws.losses
+
+    def _img(self, t: torch.Tensor) -> torch.Tensor:
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            t = t.to(torch.float32).contiguous()
+        return t
+
+    def _mat(self, t: torch.Tensor) -> torch.Tensor:
+        return t.to(torch.float32).contiguous()
+
+    def _outputs(self, ws, B: int) -> Dict[Any, torch.Tensor]:
+        """Output dict with the reference's keys / shapes / insertion order."""
+        out: Dict[Any, torch.Tensor] = {}
+        for s in (3, 2, 1, 0):
+            out['disp', s] = ws.disp[s].unsqueeze(1)
+        for fi, f in enumerate((-1, 1)):
+            out['axis_angle', 0, f] = ws.pose[fi * B:(fi + 1) * B, 0:3].unsqueeze(1)
+            out['translation', 0, f] = ws.pose[fi * B:(fi + 1) * B, 3:6].unsqueeze(1)
+            out['cam_T_cam', 0, f] = ws.T[fi]
+        for s in range(4):
+            out['depth', s] = ws.depth[s].unsqueeze(1)
+            for fi, f in enumerate((-1, 1)):
+                out['rgb', f, s] = ws.warped[s, fi]
+        return out
+
+    def losses_dict(self, losses: torch.Tensor) -> Dict[str, torch.Tensor]:
+        """Loss dict with the reference's keys (dpp.py:1074-1112); 'depth_loss' aliases the total
+        (SURVEY.md 0.4)."""
+        d: Dict[str, torch.Tensor] = {}
+        for s in range(4):
+            for j, name in enumerate(LOSS_NAMES):
+                d[f'{name}/scale_{s}'] = losses[s * 4 + j]
+        total = losses[17:18]
+        d['depth_loss'] = total
+        if self.vel_scale > 0:
+            d['velocity_loss'] = losses[16]
+        d['loss'] = total
+        return d
+
+    # ------------------------------------------------------------------------------------------
+    # backward
+    def _wgrad(self, t, desc_src, out_shape, dz, name_prefix: str, cout: int, cin: int, taps: int, **geom) -> None:
+        desc = ops.conv_desc(desc_src[0], out_shape, src_b=desc_src[1], ksize=3 if taps == 9 else 1, **geom)
+        splits = ops.wgrad_splits(desc, 1024)
+        n = cout * taps * cin
+        if t.partial is None or t.partial_elems < splits * n:
+            t.partial_elems = max(splits * n, 64 * 1024 * 1024 // 4)
+            t.partial = torch.empty(t.partial_elems, device=self.device)
+        ops.conv_wgrad(desc, dz, t.partial, splits)
+        ops.reduce_partials(t.partial, self._slot(self.g, name_prefix + '.weight', n), n, splits)
+        rows = out_shape[0] * out_shape[1] * out_shape[2]
+        nb = ops.colsum_blocks(rows)
+        ops.colsum(dz, t.colsum, rows, cout)
+        ops.reduce_partials(t.colsum, self._slot(self.g, name_prefix + '.bias', cout), cout, nb)
+
+    def backward(self, B: int) -> None:
+        """dL/d(trainable arena) for the last training forward; fills self.g (dpp.py:312)."""
+        ws = self._ws[B]
+        t = ws.train
+        c = ws.ctx
+        H, W = self.H, self.W
+        feats = ws.dfeats
+        # loss -> disparity logits and pose-decoder output ----------------------------------------
+        for s in range(4):
+            ops.photo_grad(ws.sel[s], ws.coef[s], ws.warped[s], c.rgb[0], c.sample_w, t.dpred, B, H, W)
+            ops.warp_bwd(t.dpred, ws.disp[s], c.rgb[-1], c.rgb[1], c.Kinv, ws.P, t.ddisp_up, t.dp_partial[s], self.min_depth,
+                         self.max_depth)
+            ops.disp_grad(t.ddisp_up, ws.disp[s], c.aux[s] if c.n_smooth else None, c.n_smooth, t.dz_disp[s], H, W)
+        ops.pose_bwd(t.dp_partial, 4, t.nb2, ws.pose, c.K, c.d0, c.d1, c.sample_w, self.vel_scale, t.dpose)
+        # depth decoder -----------------------------------------------------------------------------
+        dxp_in = None  # padded-domain gradient w.r.t. x[i,1] coming from upconv_{i-1}_0
+        for i in range(5):
+            hi, wi, ci = H >> i, W >> i, NUM_CH_DEC[i]
+            if i <= 3:
+                wd, _ = self._wb(f'depth_decoder/dispconv_{i}.conv', 1, ci, 9)
+                if dxp_in is None:
+                    dxp_in = t.dxp[0][:B * (hi + 2) * (wi + 2) * ci].view(B, hi + 2, wi + 2, ci)
+                    ops.dispconv_bwd_data(t.dz_disp[i], wd.view(9, ci), dxp_in, ci, accumulate=False)
+                else:
+                    ops.dispconv_bwd_data(t.dz_disp[i], wd.view(9, ci), dxp_in, ci, accumulate=True)
+                # dispconv weight + bias gradient
+                nb = ops.dispconv_wgrad_blocks(B * hi * wi)
+                ops.dispconv_wgrad(t.dz_disp[i], ws.x[i, 1], t.disp_part)
+                ops.reduce_partials(t.disp_part, self._slot(self.g, f'depth_decoder/dispconv_{i}.conv.weight', 9 * ci + 1),
+                                    9 * ci + 1, nb)
+            ops.fold_act_grad(dxp_in, ws.x[i, 1], t.dz[i, 1], h=hi, w=wi, ch=ci, border=1, pool=False, act=ACT_ELU)
+            # upconv_i_1: input = cat(up(x[i,0]), feats[i-1])
+            skip = feats[i - 1] if i > 0 else None
+            cin1 = ci + (NUM_CH_ENC[i - 1] if i > 0 else 0)
+            self._wgrad(t, (ws.x[i, 0], skip), (B, hi, wi, ci), t.dz[i, 1], f'depth_decoder/upconv_{i}_1.conv.conv', ci, cin1, 9,
+                        pad_mode=PAD_REFLECT, upsample_a=True)
+            w1, _ = self._wb(f'depth_decoder/upconv_{i}_1.conv.conv', ci, cin1, 9)
+            wt = t.wt[:ci * 9 * ci].view(ci, 9, ci)
+            ops.weight_transpose(w1, wt, ch_in_sel=ci)          # only the up(x[i,0]) half: the skip half is frozen
+            dxa = t.dxp[1][:B * (hi + 2) * (wi + 2) * ci].view(B, hi + 2, wi + 2, ci)
+            ops.conv2d(t.dz[i, 1], wt, dxa, ksize=3, pad=2)
+            ops.fold_act_grad(dxa, ws.x[i, 0], t.dz[i, 0], h=hi, w=wi, ch=ci, border=1, pool=True, act=ACT_ELU)
+            # upconv_i_0: input = x[i+1,1] (or the frozen encoder feature for i == 4)
+            src = ws.x[i + 1, 1] if i < 4 else feats[4]
+            cin0 = NUM_CH_ENC[-1] if i == 4 else NUM_CH_DEC[i + 1]
+            h2, w2 = hi >> 1, wi >> 1
+            self._wgrad(t, (src, None), (B, h2, w2, ci), t.dz[i, 0], f'depth_decoder/upconv_{i}_0.conv.conv', ci, cin0, 9,
+                        pad_mode=PAD_REFLECT)
+            if i < 4:
+                w0, _ = self._wb(f'depth_decoder/upconv_{i}_0.conv.conv', ci, cin0, 9)
+                wt = t.wt[:cin0 * 9 * ci].view(cin0, 9, ci)
+                ops.weight_transpose(w0, wt)
+                dxp_in = t.dxp[0][:B * (h2 + 2) * (w2 + 2) * cin0].view(B, h2 + 2, w2 + 2, cin0)
+                ops.conv2d(t.dz[i, 0], wt, dxp_in, ksize=3, pad=2)
+        # pose decoder --------------------------------------------------------------------------------
+        n2 = 2 * B
+        h5, w5 = H >> 5, W >> 5
+        w2_, _ = self._wb('pose_decoder/pose_2', 12, 256, 1)
+        ops.pose_head_bwd(t.dpose, ws.p1, w2_.view(12, 256), ws.pmean, t.dz_p1,
+                          self._slot(self.g, 'pose_decoder/pose_2.weight', 12 * 256).view(12, 256),
+                          self._slot(self.g, 'pose_decoder/pose_2.bias', 12))
+        self._wgrad(t, (ws.p0, None), (n2, h5, w5, 256), t.dz_p1, 'pose_decoder/pose_1', 256, 256, 9)
+        wp1, _ = self._wb('pose_decoder/pose_1', 256, 256, 9)
+        wt = t.wt[:256 * 9 * 256].view(256, 9, 256)
+        ops.weight_transpose(wp1, wt)
+        ops.conv2d(t.dz_p1, wt, t.dz_p0, ksize=3, pad=1, actgrad_src=ws.p0, actgrad_kind=ACT_RELU)
+        self._wgrad(t, (ws.sq, None), (n2, h5, w5, 256), t.dz_p0, 'pose_decoder/pose_0', 256, 256, 9)
+        wp0, _ = self._wb('pose_decoder/pose_0', 256, 256, 9)
+        ops.weight_transpose(wp0, wt)
+        ops.conv2d(t.dz_p0, wt, t.dz_sq, ksize=3, pad=1, actgrad_src=ws.sq, actgrad_kind=ACT_RELU)
+        self._wgrad(t, (ws.pf4, None), (n2, h5, w5, 256), t.dz_sq, 'pose_decoder/squeeze', 256, 512, 1, pad=0)
+
+    # ------------------------------------------------------------------------------------------
+    def adam(self, lr: float, betas=(0.9, 0.999), eps: float = 1e-8) -> None:
+        self.adam_step_count += 1
+        ops.adam_step(self.w, self.g, self.m, self.v, lr, self.adam_step_count, betas[0], betas[1], eps)
+        self._modules_stale = True
+
+    # ------------------------------------------------------------------------------------------
+    # module-level entry points (slam/slam.py:146 calls models['depth_encoder'](img)[4])
+    def run_encoder(self, which: str, x: torch.Tensor) -> List[torch.Tensor]:
+        """NCHW feature list of one encoder, as the reference's ResnetEncoder.forward returns it."""
+        self.pack_if_needed()
+        x = self._img(x.to(self.device))
+        n = x.shape[0]
+        nimg = 1 if which == 'depth_encoder' else 2
+        if x.shape[1] != 3 * nimg or x.shape[2] != self.H or x.shape[3] != self.W:
+            raise ClslamError(f'{which} input must be (N,{3 * nimg},{self.H},{self.W}), got {tuple(x.shape)}')
+        key = ('enc', which, n)
+        bufs = self._ws.get(key)
+        if bufs is None:
+            bufs = self._enc_bufs(n)
+            self._ws[key] = bufs
+        if nimg == 1:
+            stem = [(x, None, 0, n)]
+        else:
+            stem = [(x[:, :3].contiguous(), x[:, 3:].contiguous(), 0, n)]
+        feats = self._encoder(self.enc[which], bufs, n, stem)
+        return [f.permute(0, 3, 1, 2) for f in feats]
+
+    def run_pose(self, image_0: torch.Tensor, image_1: torch.Tensor) -> torch.Tensor:
+        """predict_pose (dpp.py:628-664): pose_encoder(cat(img0,img1)) -> pose_decoder; returns (n,12)."""
+        self.pack_if_needed()
+        a, b = self._img(image_0.to(self.device)), self._img(image_1.to(self.device))
+        n = a.shape[0]
+        key = ('pose', n)
+        st = self._ws.get(key)
+        if st is None:
+            E = lambda *s: torch.empty(*s, device=self.device)  # noqa: E731
+            h5, w5 = self.H >> 5, self.W >> 5
+            st = SimpleNamespace(penc=self._enc_bufs(n), sq=E(n, h5, w5, 256), p0=E(n, h5, w5, 256), p1=E(n, h5, w5, 256),
+                                 pmean=E(n, 256), pose=E(n, 12))
+            self._ws[key] = st
+        feats = self._encoder(self.enc['pose_encoder'], st.penc, n, [(a, b, 0, n)])
+        self._pose_decoder(st, feats[4])
+        return st.pose
+
+    def run_depth_decoder(self, input_features):
+        raise NotImplementedError('DepthDecoder.forward on external features is not part of the hot path; '
+                                  'use DepthPosePrediction.predict()/adapt()')
+
+    def run_pose_decoder(self, last_features):
+        raise NotImplementedError('PoseDecoder.forward on external features is not part of the hot path; '
+                                  'use DepthPosePrediction.predict_pose()')

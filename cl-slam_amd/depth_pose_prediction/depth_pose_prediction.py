@@ -1,0 +1,452 @@
+"""MI355X-native ``DepthPosePrediction``: the reference's predictor API
+(depth_pose_prediction/depth_pose_prediction.py, "dpp.py" below) on hand-written HIP kernels.
+
+What is kept identical so that slam/slam.py and main_adapt.py run unchanged:
+constructor signature + validation (dpp.py:39-127), ``models`` dict of four modules with the
+reference's state-dict keys, ``adapt`` / ``predict`` / ``predict_pose`` signatures and return
+structures (dpp.py:291-319, 530-536, 628-664), ``_set_eval/_set_train/_set_adapt``,
+``save_model`` / ``load_model`` file layout incl. ``optimizer.pth`` (dpp.py:669-749), attributes
+``device, optimizer, lr_scheduler, epoch, is_trained, batch_size, height, width, scales, frame_ids,
+min_depth, max_depth, log_path``; the caller's input dict is moved to the device in place
+(dpp.py:916-917) and ``RuntimeError('NaN loss')`` is raised like dpp.py:1115-1118.
+
+What is different by design: all arithmetic runs in ``clslam_hip.engine.Engine`` (no autograd, no
+torch.nn compute); there is NO CPU path -- constructing the predictor without a GPU / without
+libclslam_hip.so raises.  Offline pre-training / evaluation / plotting (dpp.py:219-289, 321-526,
+538-626, 829-904, 1197-1267) is outside the accelerated path and not provided.
+"""
+import math
+import shutil
+import warnings
+from pathlib import Path
+from typing import Any, Dict, Optional, Tuple, Union
+
+import numpy as np
+import torch
+from torch import Tensor, optim
+
+from clslam_hip.engine import Engine, TrainableLayout
+from depth_pose_prediction.config import DepthPosePrediction as Config
+from depth_pose_prediction.networks import DepthDecoder, PoseDecoder, ResnetEncoder
+
+
+class EngineAdam(optim.Adam):
+    """torch.optim.Adam facade over the engine's fused Adam kernel (clslam_adam_step).
+
+    It IS a torch Adam as far as ``param_groups`` / ``StepLR`` / ``state_dict`` layout go (160 params
+    in model-dict order, state for the 36 trainable ones: ids 62-89 and 152-159), but
+    ``step`` runs one kernel over the flat arena and the moments live in the engine."""
+
+    def __init__(self, params, lr: float, engine: Engine, names) -> None:
+        super().__init__(params, lr)
+        self._engine = engine
+        self._names = names  # 'model/key' per param index
+
+    def zero_grad(self, set_to_none: bool = True) -> None:  # gradients are overwritten, never accumulated
+        return None
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        g = self.param_groups[0]
+        self._engine.adam(g['lr'], g['betas'], g['eps'])
+
+    def state_dict(self):
+        sd = super().state_dict()
+        eng = self._engine
+        state = {}
+        if eng.adam_step_count > 0:
+            for idx, name in enumerate(self._names):
+                if name not in eng.layout.offset:
+                    continue
+                shape = next(s for n, _, s in eng.layout.entries if n == name)
+                off, n = eng.layout.offset[name], math.prod(shape)
+                state[idx] = {
+                    'step': torch.tensor(float(eng.adam_step_count)),
+                    'exp_avg': TrainableLayout.to_reference(eng.m[off:off + n], shape).clone(),
+                    'exp_avg_sq': TrainableLayout.to_reference(eng.v[off:off + n], shape).clone(),
+                }
+        sd['state'] = state
+        return sd
+
+    @torch.no_grad()
+    def load_state_dict(self, state_dict) -> None:
+        eng = self._engine
+        groups = state_dict['param_groups']
+        if len(groups) != 1 or len(groups[0]['params']) != len(self._names):
+            raise ValueError('loaded state dict contains a parameter group that does not match the size of '
+                             "optimizer's group")
+        for k in ('lr', 'betas', 'eps'):
+            if k in groups[0]:
+                self.param_groups[0][k] = groups[0][k]
+        eng.m.zero_()
+        eng.v.zero_()
+        step = 0
+        for idx, st in state_dict['state'].items():
+            name = self._names[int(idx)]
+            if name not in eng.layout.offset:
+                continue
+            off = eng.layout.offset[name]
+            m = TrainableLayout.to_compute(st['exp_avg'].to(eng.device, torch.float32))
+            v = TrainableLayout.to_compute(st['exp_avg_sq'].to(eng.device, torch.float32))
+            eng.m[off:off + m.numel()].copy_(m)
+            eng.v[off:off + v.numel()].copy_(v)
+            step = max(step, int(float(st['step'])))
+        eng.adam_step_count = step
+
+
+class DepthPosePrediction:
+    def __init__(self, dataset_config, config: Config, use_online: bool = False):
+        # Initialize parameters (dpp.py:41-68) ===========
+        self.config_file = config.config_file
+        self.dataset_type = dataset_config.dataset
+        self.dataset_path = dataset_config.dataset_path
+        self.height = dataset_config.height
+        self.width = dataset_config.width
+        self.train_set = config.train_set
+        self.val_set = config.val_set
+        self.resnet_depth = config.resnet_depth
+        self.resnet_pose = config.resnet_pose
+        self.resnet_pretrained = config.resnet_pretrained
+        self.scales = config.scales
+        self.learning_rate = config.learning_rate
+        self.scheduler_step_size = config.scheduler_step_size
+        self.batch_size = config.batch_size
+        self.num_workers = config.num_workers
+        self.num_epochs = config.num_epochs
+        self.min_depth = config.min_depth
+        self.max_depth = config.max_depth
+        self.disparity_smoothness = config.disparity_smoothness
+        self.velocity_loss_scaling = config.velocity_loss_scaling
+        self.mask_dynamic = config.mask_dynamic
+        self.log_path = config.log_path
+        self.save_frequency = config.save_frequency
+        self.save_val_depth = config.save_val_depth
+        self.save_val_depth_batches = config.save_val_depth_batches
+        self.multiple_gpus = config.multiple_gpus
+        self.gpu_ids = config.gpu_ids
+        self.load_weights_folder = config.load_weights_folder
+        self.use_wandb = False
+
+        self.is_trained = False
+        self.frame_ids = (0, -1, 1)
+        self.num_pose_frames = 2
+        self.device = _select_device()
+
+        # Dependent parameters (dpp.py:79-127), same checks and messages ==================
+        if self.load_weights_folder is not None:
+            self.load_weights_folder = Path(self.load_weights_folder).absolute()
+        if isinstance(self.train_set, list):
+            self.train_set = tuple(self.train_set)
+        if isinstance(self.val_set, list):
+            self.val_set = tuple(self.val_set)
+        if dataset_config.dataset == 'Kitti':
+            if isinstance(self.val_set, int):
+                self.val_set = (self.val_set,)
+            if isinstance(self.train_set, str):
+                if self.train_set != 'all':
+                    raise ValueError('train_set of KITTI only accepts these strings: ["all"]')
+                self.train_set = tuple(s for s in range(11) if s not in self.val_set and s != 3)
+            elif isinstance(self.train_set, int):
+                self.train_set = (self.train_set,)
+            if not (isinstance(self.train_set, tuple) and isinstance(self.train_set[0], int)):
+                raise ValueError('Passed invalid value for train_set')
+            if not (isinstance(self.val_set, tuple) and isinstance(self.val_set[0], int)):
+                raise ValueError('Passed invalid value for val_set')
+        elif dataset_config.dataset in ['Cityscapes', 'RobotCar']:
+            if isinstance(self.train_set, str):
+                self.train_set = (self.train_set,)
+            if isinstance(self.val_set, str):
+                self.val_set = (self.val_set,)
+            if not (isinstance(self.train_set, tuple) and isinstance(self.train_set[0], str)):
+                raise ValueError('Passed invalid value for train_set')
+            if not (isinstance(self.val_set, tuple) and isinstance(self.val_set[0], str)):
+                raise ValueError('Passed invalid value for val_set')
+        if self.multiple_gpus:
+            # the reference wraps the nets in single-process nn.DataParallel (dpp.py:178-181, pre-training
+            # only, disabled in config_adapt.yaml:31); here multi-GPU is one process per GPU, see
+            # enable_data_parallel()
+            raise ValueError('multiple_gpus (nn.DataParallel) is not used on MI355X: launch one process per GPU and '
+                             'call enable_data_parallel()')
+        if self.gpu_ids is not None and len(self.gpu_ids) > 1:
+            raise ValueError('Passed multiple GPU IDs without activating multi-GPU support.')
+        if self.gpu_ids is None:
+            self.gpu_ids = (self.device.index or 0,)
+        if use_online:
+            raise ValueError('use_online (dual network) is never enabled by the reference SLAM driver '
+                             '(slam/slam.py:39) and is not part of the accelerated path')
+        if self.mask_dynamic:
+            raise ValueError('mask_dynamic=True is the pre-training configuration; the accelerated path implements '
+                             'the adaptation configuration (mask_dynamic=False, config_adapt.yaml:26)')
+        if tuple(self.scales) != (0, 1, 2, 3):
+            raise ValueError('The accelerated path implements scales=(0, 1, 2, 3)')
+        # =================================================
+
+        # Networks (parameter containers) + engine ========
+        self.models = {}
+        self.models['depth_encoder'] = ResnetEncoder(self.resnet_depth, self.resnet_pretrained)
+        self.models['depth_decoder'] = DepthDecoder(self.models['depth_encoder'].num_ch_encoder, self.scales)
+        self.models['pose_encoder'] = ResnetEncoder(self.resnet_pose, self.resnet_pretrained, self.num_pose_frames)
+        self.models['pose_decoder'] = PoseDecoder(self.models['pose_encoder'].num_ch_encoder, num_input_features=1,
+                                                  num_frames_to_predict_for=2)
+        self.use_online = False
+        self.online_models = {}
+        self.engine = Engine(self.height, self.width, self.device, min_depth=self.min_depth, max_depth=self.max_depth,
+                             disparity_smoothness=self.disparity_smoothness,
+                             velocity_loss_scaling=self.velocity_loss_scaling)
+        for m in self.models.values():
+            m.to(self.device)
+        self.engine.bind(self.models)
+        self.engine.pack()
+
+        self.parameters_to_train = []
+        names = []
+        for model_name, m in self.models.items():
+            for n, p in torch.nn.Module.named_parameters(m):
+                self.parameters_to_train.append(p)
+                names.append(f'{model_name}/{n}')
+        self.online_parameters_to_train = []
+
+        # Optimizer (dpp.py:203-210) ======================
+        self.optimizer = EngineAdam(self.parameters_to_train, self.learning_rate, self.engine, names)
+        self.lr_scheduler = optim.lr_scheduler.StepLR(self.optimizer, self.scheduler_step_size, 0.1)
+        self.epoch = 0
+        self.online_optimizer = None
+        self.train_loader, self.val_loader = None, None
+
+        self._dp = None
+        self._injected_noise = None
+        self.zero_copy_outputs = False
+
+    # ============================================================
+    # Data-parallel replay minibatch (new functionality; the reference has no multi-GPU adaptation)
+
+    def enable_data_parallel(self, global_batch_size: int, shard_offset: int, process_group=None) -> None:
+        """One process per GPU (torch.distributed, backend 'nccl' = RCCL).  Every rank calls
+        ``adapt`` with ITS contiguous shard of the (online + replay) minibatch; the rank whose shard
+        starts at 0 holds the online sample.  Loss terms use the global batch size, the flat
+        gradient arena is sum-all-reduced once per step, Adam runs identically on every rank."""
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            raise RuntimeError('torch.distributed is not initialised')
+        self._dp = dict(group=process_group, global_batch=int(global_batch_size), offset=int(shard_offset), dist=dist)
+
+    def set_tie_break_noise(self, noise: Optional[Dict[int, Tensor]]) -> None:
+        """Parity testing only: inject the per-scale tie-break tensors (B,2,H,W) that the reference
+        draws with torch.randn(...) * 1e-5 (dpp.py:1055-1056).  None -> draw on the device."""
+        self._injected_noise = noise
+
+    # ============================================================
+    # Training / validation: offline, outside the accelerated path
+
+    def train(self, *args, **kwargs) -> None:
+        raise NotImplementedError('offline pre-training (dpp.py:219-289) is outside the MI355X hot path; '
+                                  'pre-train with the reference and load the checkpoint here')
+
+    def adapt(self,
+              online_data: Dict[Any, Tensor],
+              training_data: Optional[Dict[Any, Tensor]] = None,
+              online_index: int = 0,
+              steps: int = 1,
+              online_loss_weight: Optional[float] = None):
+        # dpp.py:297-305
+        if online_loss_weight is None:
+            loss_weights = None
+        elif self.batch_size == 1:
+            loss_weights = torch.ones(1, device=self.device)
+        else:
+            loss_weights = torch.empty(self.batch_size, device=self.device)
+            buffer_loss_weight = (1 - online_loss_weight) / (self.batch_size - 1)
+            loss_weights[:] = buffer_loss_weight
+            loss_weights[online_index] = online_loss_weight
+
+        if training_data is not None:
+            self._set_adapt(freeze_encoder=True)
+            self.engine.pack_if_needed()
+            for _ in range(steps):
+                outputs_eval, losses = self._process_batch(training_data, loss_weights, train=True)
+                self.optimizer.zero_grad()
+                self._backward(training_data)
+                self.optimizer.step()
+        else:
+            self._set_eval()
+            self.engine.pack_if_needed()
+            outputs_eval, losses = self._process_batch(online_data, loss_weights, train=False)
+        return outputs_eval, losses
+
+    # ============================================================
+    # Predict functions
+
+    def predict(self, batch) -> Dict[Any, Tensor]:
+        if not self.is_trained:
+            warnings.warn('The model has not been trained yet.', RuntimeWarning)
+        self._set_eval()
+        self.engine.pack_if_needed()
+        outputs, _ = self._process_batch(batch, train=False)
+        return outputs
+
+    def predict_pose(
+            self,
+            image_0: Tensor,
+            image_1: Tensor,
+            as_numpy: bool = True,
+            use_online: bool = False,
+    ) -> Tuple[Union[Tensor, np.ndarray], Union[Tensor, np.ndarray]]:
+        if not self.is_trained:
+            warnings.warn('The model has not been trained yet.', RuntimeWarning)
+        if use_online:
+            raise ValueError('use_online is not part of the accelerated path')
+        if len(image_0.shape) == 3:
+            image_0 = image_0.unsqueeze(dim=0)
+        if len(image_1.shape) == 3:
+            image_1 = image_1.unsqueeze(dim=0)
+        self._set_eval()
+        pose = self.engine.run_pose(image_0, image_1)           # (n,12), frame-0 slice = [:, :6]
+        n = pose.shape[0]
+        # invert=False (dpp.py:655): T = translate(t) * rot(axis_angle); frame idx 1 of pose_to_proj
+        from clslam_hip import ops
+        pad = torch.zeros(2 * n, 12, device=self.device)
+        pad[n:] = pose
+        eye = torch.eye(4, device=self.device).repeat(n, 1, 1)
+        T = torch.empty(2, n, 4, 4, device=self.device)
+        P = torch.empty(2, n, 3, 4, device=self.device)
+        ops.pose_to_proj(pad, eye, T, P)
+        transformation = T[1].clone()
+        cov_matrix = torch.eye(6, device=self.device)
+        if as_numpy:
+            transformation = transformation.squeeze().cpu().detach().numpy()
+            cov_matrix = cov_matrix.cpu().detach().numpy()
+        return transformation, cov_matrix
+
+    # ============================================================
+    # Save / load (dpp.py:669-749): same files, same keys
+
+    def save_model(self) -> None:
+        save_folder = Path(self.log_path) / 'models' / f'weights_{self.epoch:03}'
+        save_folder.mkdir(parents=True, exist_ok=True)
+        for model_name, model in self.models.items():
+            to_save = model.state_dict()
+            if 'encoder' in model_name:
+                # the reference stores Tensor(self.height) / Tensor(self.width): float tensors of
+                # LENGTH height/width with unspecified content; same shape, zeros.
+                to_save['height'] = torch.zeros(self.height)
+                to_save['width'] = torch.zeros(self.width)
+            torch.save(to_save, save_folder / f'{model_name}.pth')
+        torch.save({'optimizer': self.optimizer.state_dict(), 'scheduler': self.lr_scheduler.state_dict()},
+                   save_folder / 'optimizer.pth')
+        if self.config_file is not None and Path(self.config_file).exists():
+            shutil.copy(self.config_file, Path(self.log_path) / 'config.yaml')
+        print(f'Saved model to: {save_folder}')
+
+    def load_model(self, load_optimizer: bool = True) -> None:
+        if self.load_weights_folder is None:
+            print('Weights folder required to load the model is not specified.')
+        if not self.load_weights_folder.exists():
+            print(f'Cannot find folder: {self.load_weights_folder}')
+        print(f'Load model from: {self.load_weights_folder}')
+        for model_name, model in self.models.items():
+            path = self.load_weights_folder / f'{model_name}.pth'
+            pretrained_dict = torch.load(path, map_location=self.device)
+            model_dict = model.state_dict()
+            pretrained_dict = {k: v for k, v in pretrained_dict.items() if k in model_dict}
+            if len(pretrained_dict.keys()) == 0:
+                raise RuntimeError(f'No fitting weights found in: {path}')
+            model_dict.update(pretrained_dict)
+            model.load_state_dict(model_dict)
+        self.is_trained = True
+        self.engine.pack()
+        if load_optimizer:
+            optimizer_load_path = self.load_weights_folder / 'optimizer.pth'
+            try:
+                optimizer_dict = torch.load(optimizer_load_path, map_location=self.device)
+                if 'optimizer' in optimizer_dict:
+                    self.optimizer.load_state_dict(optimizer_dict['optimizer'])
+                    self.lr_scheduler.load_state_dict(optimizer_dict['scheduler'])
+                    self.epoch = self.lr_scheduler.last_epoch
+                    print(f'Restored optimizer and LR scheduler (resume from epoch {self.epoch}).')
+                else:
+                    self.optimizer.load_state_dict(optimizer_dict)
+                    print('Restored optimizer (legacy mode).')
+            except Exception:  # pylint: disable=broad-except
+                print('Cannot find matching optimizer weights, so the optimizer is randomly initialized.')
+
+    def sync_weights(self) -> None:
+        """Make direct attribute reads of module parameters see the adapted weights (state_dict(),
+        parameters() and save_model() do this implicitly)."""
+        self.engine.sync_modules()
+
+    # ============================================================
+    # Auxiliary functions (dpp.py:797-827)
+
+    def _set_train(self) -> None:
+        for m in self.models.values():
+            m.train()
+
+    def _set_eval(self) -> None:
+        for m in self.models.values():
+            m.eval()
+
+    def _set_adapt(self, freeze_encoder: bool = True) -> None:
+        if not freeze_encoder:
+            raise ValueError('the accelerated path implements freeze_encoder=True (dpp.py:308)')
+        for model_name, model in self.models.items():
+            model.eval()
+            for name, param in torch.nn.Module.named_parameters(model):
+                if name.find('bn') != -1:
+                    param.requires_grad = False
+                if 'encoder' in model_name:
+                    param.requires_grad = False
+
+    # ============================================================
+    def _sample_weights(self, B: int, loss_sample_weights: Optional[Tensor]):
+        """dpp.py:1031-1032 and the broadcasting of a (batch_size,) weight vector against the actual
+        batch (equal sizes, or an actual batch of 1 which sees the SUM of the weights)."""
+        if self._dp is not None:
+            gb = self._dp['global_batch']
+            w = torch.full((gb,), 1.0 / gb, device=self.device) if loss_sample_weights is None else loss_sample_weights
+            local = w[self._dp['offset']:self._dp['offset'] + B].contiguous()
+            return local, (w.contiguous() if self._dp['offset'] == 0 else None)
+        if loss_sample_weights is None:
+            loss_sample_weights = torch.ones(self.batch_size, device=self.device) / self.batch_size
+        if loss_sample_weights.numel() == B:
+            w = loss_sample_weights.to(self.device, torch.float32).contiguous()
+        elif B == 1:
+            w = loss_sample_weights.to(self.device, torch.float32).sum().reshape(1)
+        else:
+            raise RuntimeError(f'The size of tensor a ({B}) must match the size of tensor b '
+                               f'({loss_sample_weights.numel()}) at non-singleton dimension 0')
+        return w, w
+
+    def _process_batch(self, inputs: Dict[Any, Tensor], loss_sample_weights: Optional[Tensor] = None,
+                       use_online: bool = False, train: bool = False):
+        for key, val in inputs.items():  # mutates the caller's dict, like dpp.py:916-917
+            inputs[key] = val.to(self.device)
+        B = inputs['rgb_aug', 0, 0].shape[0]
+        sample_w, smooth_w = self._sample_weights(B, loss_sample_weights)
+        outputs, losses = self.engine.forward(inputs, train=train, sample_w=sample_w, smooth_w=smooth_w,
+                                              noise=self._injected_noise)
+        if self._dp is not None:
+            self._dp['dist'].all_reduce(losses, group=self._dp['group'])
+        loss_dict = self.engine.losses_dict(losses if self.zero_copy_outputs else losses.clone())
+        if np.isnan(loss_dict['loss'].item()):  # dpp.py:1115-1118 (also the step's only host sync)
+            for k, v in loss_dict.items():
+                print(k, v.item())
+            raise RuntimeError('NaN loss')
+        if not self.zero_copy_outputs:
+            outputs = {k: v.clone() for k, v in outputs.items()}
+        return outputs, loss_dict
+
+    def _backward(self, inputs: Dict[Any, Tensor]) -> None:
+        B = inputs['rgb_aug', 0, 0].shape[0]
+        self.engine.backward(B)
+        if self._dp is not None:
+            self._dp['dist'].all_reduce(self.engine.g, group=self._dp['group'])
+
+
+def _select_device() -> torch.device:
+    from clslam_hip import _lib
+    lib = _lib.get_lib()  # raises when libclslam_hip.so is missing: no CPU fallback
+    if lib.is_device:
+        if not torch.cuda.is_available():
+            raise RuntimeError('libclslam_hip.so needs an MI355X (no GPU visible); there is no CPU fallback')
+        return torch.device('cuda', torch.cuda.current_device())
+    return torch.device('cpu')  # only reachable with the test emulator installed by tests/emu_util.py
