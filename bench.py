@@ -1,0 +1,191 @@
+#!/usr/bin/env python
+"""Headline benchmark: online-adaptation frames/sec of the depth/pose hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--replay R] [--height 192 --width 640]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one `DepthPosePrediction.adapt(online, training, steps=1)`: forward of both networks,
+view synthesis + loss, hand-written backward, fused Adam -- on a synthetic minibatch of 1 online
+triplet + R replayed triplets that is already resident in HBM (BASELINE.json metric).
+N = 1 runs BASELINE config 3 (R = 4, B = 5, the configuration the 30 frames/s target is quoted on).
+N > 1 shards a minibatch of B = 1 + 4N triplets data-parallel (rank 0: online + 4, others 4 each;
+N = 8 is BASELINE config 4, R = 32) with ONE sum-all-reduce of the flat gradient arena per step over
+RCCL/xGMI.  `value` counts frames of 5 triplets: value = steps/s * B/5, so N = 1 is plain frames/s and
+per-GPU work stays fixed as N grows ("weak").
+
+Rank 0 prints ONE JSON line (contract in the task description) with `roofline` (dominant kernel:
+the fp32-MFMA implicit-GEMM conv, algorithmic FLOPs / HIP-event launch time vs the 157.3 TFLOP/s
+fp32 matrix peak) and `cpu_baseline` (the oracle's torch-CPU restatement of the same step, timed on
+this box's host cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT / 'cl-slam_amd'))
+sys.path.insert(0, str(ROOT))
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+
+import torch  # noqa: E402
+
+FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4_f32
+FRAME_TRIPLETS = 5              # a "frame" of BASELINE config 3: 1 online + 4 replay triplets
+
+
+def build_predictor(H, W, B_cfg):
+    from types import SimpleNamespace
+    from clslam_hip import synth
+    from depth_pose_prediction import Config, DepthPosePrediction
+    ds = SimpleNamespace(dataset='Kitti', config_file=Path('x.yaml'), dataset_path=None, scales=(0, 1, 2, 3), height=H,
+                         width=W, frame_ids=(0, -1, 1))
+    cfg = Config(config_file=Path('x.yaml'), train_set='all', val_set=0, resnet_depth=18, resnet_pose=18,
+                 resnet_pretrained=False, scales=(0, 1, 2, 3), learning_rate=1e-4, scheduler_step_size=15,
+                 batch_size=B_cfg, num_workers=0, num_epochs=1, min_depth=0.1, max_depth=None, disparity_smoothness=1e-3,
+                 velocity_loss_scaling=0.05, mask_dynamic=False, log_path=Path('/tmp/clslam_bench'), save_frequency=-1,
+                 save_val_depth=False, save_val_depth_batches=0, multiple_gpus=False, gpu_ids=None,
+                 load_weights_folder=None, use_wandb=False)
+    p = DepthPosePrediction(ds, cfg)
+    for name, m in p.models.items():  # random-init weights of the reference architecture (closed form)
+        m.load_state_dict(synth.fill_state_dict(torch.nn.Module.state_dict(m), 0, name))
+    p.is_trained = True
+    return p
+
+
+def cpu_baseline(H, W, B, budget_s=25.0):
+    """The oracle (torch-CPU port of the reference step, validated against the reference's golden
+    vectors) on this host's cores; bounded sample."""
+    from clslam_hip import synth
+    from oracle import OraclePredictor
+    threads = torch.get_num_threads()
+    o = OraclePredictor(H, W, B)
+    for name, m in o.models.items():
+        m.load_state_dict(synth.fill_state_dict(m.state_dict(), 0, name))
+    batch = synth.make_batch(B, H, W, seed=0)
+    t_all = time.time()
+    o.adapt(batch, steps=1)  # warm-up
+    times = []
+    while len(times) < 5 and (time.time() - t_all) < budget_s:
+        t0 = time.time()
+        o.adapt(batch, steps=1)
+        times.append(time.time() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return {'value': round(1.0 / med, 4), 'unit': 'frames/s', 'cores': threads, 'kind': 'port',
+            'sample': f'{len(times)} adapt steps (1 warm-up) of the same B={B} {H}x{W} minibatch, torch {torch.__version__} '
+                      f'CPU fp32, median {med:.3f} s/step'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--replay', type=int, default=None, help='replay triplets K (default 4 per GPU)')
+    ap.add_argument('--height', type=int, default=192)
+    ap.add_argument('--width', type=int, default=640)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+    H, W, N = args.height, args.width, args.gpus
+
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != N:
+        raise SystemExit(f'--gpus {N} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {N}')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    dist = None
+    if N > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=dev)
+
+    K = args.replay if args.replay is not None else 4 * N
+    B = 1 + K
+    # contiguous shards, rank 0 holds the online sample (+ the remainder)
+    base, rem = divmod(B, N)
+    counts = [base + (1 if r < rem else 0) for r in range(N)]
+    offset = sum(counts[:rank])
+    Bl = counts[rank]
+
+    from clslam_hip import ops, synth
+    p = build_predictor(H, W, B if N == 1 else Bl)
+    if N > 1:
+        p.enable_data_parallel(B, offset)
+    full = synth.make_batch(B, H, W, seed=0)
+    batch = {k: v[offset:offset + Bl].to(dev) for k, v in full.items()}
+
+    def step():
+        return p.adapt(None, batch, steps=1)
+
+    def sync():
+        if N > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        outputs, losses = step()
+    sync()
+    dt = time.perf_counter() - t0
+    if N > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms = dt / args.steps * 1e3
+    value = (args.steps / dt) * (B / FRAME_TRIPLETS)
+
+    # ---- roofline of the dominant kernel (instrumented extra step, outside the timed region) ------
+    roof = None
+    if rank == 0:
+        ops.PROFILE = []
+        step()
+        torch.cuda.synchronize()
+        agg = {}
+        for kind, cfg, flops, e0, e1 in ops.PROFILE:
+            a = agg.setdefault((kind, cfg), [0.0, 0.0, 0])
+            a[0] += flops
+            a[1] += e0.elapsed_time(e1) * 1e-3
+            a[2] += 1
+        ops.PROFILE = None
+        names = {0: '128x64x32/32x32x2', 1: '64x64x32/32x32x2', 2: '32x32x32/16x16x4', 3: '64x32x32/16x16x4',
+                 4: '128x16x16/16x16x4', 5: '64x32x16/16x16x4', 6: '128x16x32/16x16x4'}
+        (kind, cfg), (fl, tt, cnt) = max(agg.items(), key=lambda kv: kv[1][1])
+        all_fl = sum(a[0] for a in agg.values())
+        all_t = sum(a[1] for a in agg.values())
+        roof = {'bound': 'mfma', 'achieved': round(fl / tt / 1e12, 2), 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': round(fl / tt / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': None,
+                'kernel': f'conv_igemm_kernel<{names[cfg]}>', 'launches_per_step': cnt,
+                'avg_launch_us': round(tt / cnt * 1e6, 2), 'flops_per_launch_avg': fl / cnt,
+                'all_conv_launches': {'achieved': round(all_fl / all_t / 1e12, 2), 'time_ms_per_step': round(all_t * 1e3, 3),
+                                      'gflop_per_step': round(all_fl / 1e9, 2)}}
+    cpu = None
+    if rank == 0 and N == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(H, W, B)
+    if rank == 0:
+        line = {
+            'metric': 'online-adapt frames/sec @192x640 (1 triplet + K replay)',
+            'value': round(value, 3), 'unit': 'frames/s', 'n_gpus': N, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'DepthPosePrediction.adapt(steps=1), {H}x{W}, 1 online + K={K} replay triplets '
+                                   f'(global batch {B}); ResNet-18 depth+pose nets, closed-form random-init weights; '
+                                   f'a frame = {FRAME_TRIPLETS} triplets (value = steps/s * B/{FRAME_TRIPLETS})',
+                       'global_batch': B, 'replay_k': K, 'height': H, 'width': W, 'adapt_steps_per_frame': 1,
+                       'parallelism': f'dp{N}' if N > 1 else 'single', 'shards': counts,
+                       'loss': float(losses['loss'])},
+            'roofline': roof, 'cpu_baseline': cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if N > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -41,6 +41,7 @@ _SIGNATURES = {
     'clslam_version': [],
     'clslam_is_device_build': [],
     'clslam_conv2d': [C.POINTER(ConvDesc), C.c_void_p],
+    'clslam_conv2d_pick_config': [C.POINTER(ConvDesc)],
     'clslam_weight_transpose': [fptr, fptr, i32, i32, i32, i32, C.c_void_p],
     'clslam_fold_act_grad': [fptr, fptr, fptr, i32, i32, i32, i32, i32, i32, i32, i32, C.c_void_p],
     'clslam_wgrad_splits': [C.POINTER(ConvDesc), i32],

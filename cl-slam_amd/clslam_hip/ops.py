@@ -8,6 +8,10 @@ from . import _lib
 from ._lib import ACT_ELU, ACT_NONE, ACT_RELU, PAD_REFLECT, PAD_ZERO  # noqa: F401
 
 
+# bench.py sets this to a list to collect (kernel, tile config, algorithmic flops, start, end) per conv launch
+PROFILE = None
+
+
 def _stream(t: torch.Tensor):
     if t.is_cuda:
         return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
@@ -49,6 +53,14 @@ def conv2d(src_a, weight, out, *, src_b=None, scale=None, shift=None, residual=N
     d = _lib.ConvDesc(_p(src_a), _p(src_b), _p(weight), _p(scale), _p(shift), _p(residual), _p(out),
                       B, Hi, Wi, Ca, Cb, Ho, Wo, Cout, ksize, stride, pad, pad_mode, int(upsample_a), act, config,
                       _p(actgrad_src), actgrad_kind)
+    if PROFILE is not None:
+        cfg = config if config >= 0 else _lib.get_lib().cdll.clslam_conv2d_pick_config(C.byref(d))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _lib.get_lib().call('clslam_conv2d', C.byref(d), _stream(out))
+        e1.record()
+        PROFILE.append(('conv_igemm', cfg, 2.0 * B * Ho * Wo * Cout * ksize * ksize * (Ca + Cb), e0, e1))
+        return out
     _lib.get_lib().call('clslam_conv2d', C.byref(d), _stream(out))
     return out
 

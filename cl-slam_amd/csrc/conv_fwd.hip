@@ -238,6 +238,19 @@ using namespace clslam;
 //   4: 128x16x16  16x16x4  4x1 (2x1 tiles/wave)          Cout == 16, Cin % 32 != 0
 //   5:  64x32x16  16x16x4  2x2                           BK = 16 fallback
 //   6: 128x16x32  16x16x4  4x1                           Cout == 16, Cin % 32 == 0
+extern "C" int clslam_conv2d_pick_config(const clslam_conv_desc* d) {
+    const int Cin = d->ch_a + d->ch_b;
+    const int M = d->batch * d->out_h * d->out_w;
+    const bool bk32 = (Cin % 32 == 0) && (d->ch_b == 0 || d->ch_a % 32 == 0);
+    if (d->ch_out % 32 != 0) return bk32 ? 6 : 4;
+    if (!bk32) return 5;
+    if (d->ch_out == 32) return 3;
+    // measured on MI355X (tools/bench_conv.py): the 32x32 / 16x16x4 tiling wins or ties everywhere
+    // except the widest-M 64-channel layers, where 64x32 is ~5 % ahead
+    if (d->ch_out == 64 && M >= 30000) return 3;
+    return 2;
+}
+
 extern "C" int clslam_conv2d(const clslam_conv_desc* d, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     CLSLAM_REQUIRE(d && d->src_a && d->weight && d->out, "conv2d: null pointer");
@@ -260,16 +273,7 @@ extern "C" int clslam_conv2d(const clslam_conv_desc* d, void* stream_) {
     if (k.M == 0) return CLSLAM_OK;
     int cfg = d->config;
     const bool bk32 = (Cin % 32 == 0) && (d->ch_b == 0 || d->ch_a % 32 == 0);
-    if (cfg < 0) {
-        if (d->ch_out % 32 != 0) cfg = bk32 ? 6 : 4;
-        else if (!bk32) cfg = 5;
-        else if (d->ch_out == 32) cfg = 3;
-        else {
-            const long blocks0 = (long)cdiv(k.M, 128) * cdiv(d->ch_out, 64);
-            const long blocks1 = (long)cdiv(k.M, 64) * cdiv(d->ch_out, 64);
-            cfg = blocks0 >= 1024 ? 0 : (blocks1 >= 512 ? 1 : 2);
-        }
-    }
+    if (cfg < 0) cfg = clslam_conv2d_pick_config(d);
     const bool need32 = (cfg <= 3 || cfg == 6);
     if (need32 && !bk32) { set_error("conv2d: config %d needs channel multiples of 32", cfg); return CLSLAM_ERR_INVALID; }
     if ((cfg == 0 || cfg == 1) && d->ch_out % 32 != 0) { set_error("conv2d: config %d needs Cout %% 32 == 0", cfg); return CLSLAM_ERR_INVALID; }

@@ -70,6 +70,8 @@ typedef struct clslam_conv_desc {
     int32_t actgrad_kind;
 } clslam_conv_desc;
 int clslam_conv2d(const clslam_conv_desc* desc, void* stream);
+/* the tile configuration clslam_conv2d uses for desc->config < 0 (profiling / reporting) */
+int clslam_conv2d_pick_config(const clslam_conv_desc* desc);
 
 /* ---------------------------------------------------------------------------------------------
  * Backward of the trainable convolutions -- replaces autograd's convolution_backward,
