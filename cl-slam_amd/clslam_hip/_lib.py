@@ -7,6 +7,8 @@ the CPU emulator through ``install_library_for_tests``; nothing in the product c
 """
 import ctypes as C
 from pathlib import Path
+
+import torch  # noqa: F401  -- FIRST: the library must bind to the HIP runtime torch ships (same libamdhip64)
 from typing import Optional
 
 LIB_PATH = Path(__file__).resolve().parents[1] / 'lib' / 'libclslam_hip.so'
@@ -66,6 +68,7 @@ _SIGNATURES = {
     'clslam_photo_map': [fptr, fptr, fptr, fptr, i32, i32, i32, i32, C.c_void_p],
     'clslam_automask_blocks': [i32, i32],
     'clslam_automask': [fptr, fptr, fptr, fptr, fptr, i32, i32, i32, C.c_void_p],
+    'clslam_disp_mean_chunks': [],
     'clslam_disp_mean': [fptr, fptr, i32, i32, C.c_void_p],
     'clslam_loss_finalize': [C.POINTER(LossDesc), C.c_void_p],
     'clslam_photo_grad': [fptr, fptr, fptr, fptr, fptr, fptr, i32, i32, i32, C.c_void_p],

@@ -242,7 +242,7 @@ class Engine:
         ws.sel = torch.empty(4, B, H, W, dtype=torch.uint8, device=dev)
         ws.nblk = ops.automask_blocks(H, W)
         ws.partial = E(4, B, ws.nblk)
-        ws.means = E(4, B)
+        ws.means = E(4, B, ops.disp_mean_chunks())
         ws.losses = E(18)
         ws.noise = E(4, B, 2, H, W)
         ws.train = None

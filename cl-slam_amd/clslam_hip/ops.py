@@ -212,6 +212,10 @@ def automask(idmap, noise, rpmap, sel, partial, batch, H, W):
                         H, W, _stream(idmap))
 
 
+def disp_mean_chunks() -> int:
+    return _lib.get_lib().cdll.clslam_disp_mean_chunks()
+
+
 def disp_mean(disp, means):
     B = disp.shape[0]
     _lib.get_lib().call('clslam_disp_mean', _p(disp), _p(means), B, disp.numel() // B, _stream(disp))

@@ -239,13 +239,29 @@ static int launch_wgrad(WgradK k, int splits, hipStream_t stream) {
     return check_launch("conv_wgrad");
 }
 
-// out[i] = sum_s partial[s][i]  (fixed order -> deterministic)
-__global__ void reduce_partials_kernel(const float* __restrict__ partial, float* __restrict__ out, size_t n,
-                                       int splits, float scale) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+// out[i] = scale * sum_s partial[s][i].  IL outputs x KL split-lanes per block: lane kl sums splits
+// kl, kl+KL, ... in order, then the KL partial sums are added in order (deterministic; also fast when
+// n is tiny and splits is large, e.g. bias gradients).
+template <int IL>
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, float* __restrict__ out,
+                                                             size_t n, int splits, float scale) {
+    constexpr int KL = 256 / IL;
+    __shared__ float red[256];
+    const int il = threadIdx.x % IL, kl = threadIdx.x / IL;
+    for (size_t i0 = (size_t)blockIdx.x * IL; i0 < n; i0 += (size_t)gridDim.x * IL) {
+        const size_t i = i0 + il;
         float s = 0.f;
-        for (int k = 0; k < splits; ++k) s += partial[(size_t)k * n + i];
-        out[i] = s * scale;
+        if (i < n)
+            for (int k = kl; k < splits; k += KL) s += partial[(size_t)k * n + i];
+        red[threadIdx.x] = s;
+        __syncthreads();
+        if (kl == 0 && i < n) {
+            float t = 0.f;
+#pragma unroll
+            for (int q = 0; q < KL; ++q) t += red[q * IL + il];
+            out[i] = t * scale;
+        }
+        __syncthreads();
     }
 }
 
@@ -346,12 +362,17 @@ extern "C" int clslam_conv_wgrad(const clslam_conv_desc* d, const float* dz, flo
 extern "C" int clslam_reduce_partials(const float* partial, float* out, size_t n, int splits, float scale, void* stream) {
     CLSLAM_REQUIRE(partial && out, "reduce_partials: null");
     if (n == 0) return CLSLAM_OK;
-    const int blocks = (int)std::min<size_t>(2048, (n + 255) / 256);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, partial, out, n, splits, scale);
+    if (n >= 16384 || splits <= 8) {
+        const int blocks = (int)std::min<size_t>(4096, (n + 63) / 64);
+        hipLaunchKernelGGL(reduce_partials_kernel<64>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, partial, out, n, splits, scale);
+    } else {
+        const int blocks = (int)std::min<size_t>(4096, (n + 15) / 16);
+        hipLaunchKernelGGL(reduce_partials_kernel<16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, partial, out, n, splits, scale);
+    }
     return check_launch("reduce_partials");
 }
 
-extern "C" int clslam_colsum_blocks(int rows) { return std::max(1, std::min(1024, cdiv(rows, 256))); }
+extern "C" int clslam_colsum_blocks(int rows) { return std::max(1, std::min(512, cdiv(rows, 512))); }
 
 // partial must hold clslam_colsum_blocks(rows)*ch floats; follow with clslam_reduce_partials.
 extern "C" int clslam_colsum(const float* x, float* partial, int rows, int ch, void* stream) {

@@ -93,23 +93,27 @@ __global__ __launch_bounds__(256) void automask_kernel(const float* __restrict__
     if (threadIdx.x == 0) partial[(size_t)b * gridDim.x + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
-// mean of each sample's disparity map: means[b] (grid B, block 256)
-__global__ __launch_bounds__(256) void disp_mean_kernel(const float* __restrict__ disp, float* __restrict__ means, int hw) {
+// per-sample disparity sums in DM_CHUNKS pieces: psum[b][chunk] (grid (DM_CHUNKS, B)); the finalize
+// kernel adds the chunks in order and divides by h*w.
+constexpr int DM_CHUNKS = 32;
+__global__ __launch_bounds__(256) void disp_mean_kernel(const float* __restrict__ disp, float* __restrict__ psum, int hw) {
     __shared__ float red[4];
-    const int b = blockIdx.x;
+    const int b = blockIdx.y;
+    const int per = (hw + DM_CHUNKS - 1) / DM_CHUNKS;
+    const int p0 = blockIdx.x * per, p1 = min(hw, p0 + per);
     float s = 0.f;
-    for (int p = threadIdx.x; p < hw; p += 256) s += disp[(size_t)b * hw + p];
+    for (int p = p0 + (int)threadIdx.x; p < p1; p += 256) s += disp[(size_t)b * hw + p];
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) means[b] = (red[0] + red[1] + red[2] + red[3]) / (float)hw;
+    if (threadIdx.x == 0) psum[(size_t)b * DM_CHUNKS + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
 struct FinalizeArgs {
     const float* partial[4];     // [B][nblk] per scale
     const float* disp[4];        // (B,h_s,w_s)
     const float* rgb0[4];        // target pyramid ('rgb',0,s): (B,3,h_s,w_s)
-    const float* means[4];       // per-sample disparity means
+    const float* means[4];       // per-sample disparity chunk sums [B][DM_CHUNKS]
     const float* pose;           // (2B,12)
     const double* dist0;         // |relative_distance(0)| source, (B)
     const double* dist1;
@@ -129,8 +133,16 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(FinalizeArgs a) {
     __shared__ float s_sm[4 * FIN_MAXB];      // weighted smoothness terms
     __shared__ float s_ds[4 * FIN_MAXB];      // per-term contributions to sum_q D[q]*disp[q]
     __shared__ float s_vel[FIN_MAXB];
+    __shared__ float s_mean[4 * FIN_MAXB];
     const int tid = threadIdx.x;
     const float invHW = 1.f / ((float)a.H * (float)a.W);
+    for (int pr = tid; pr < 4 * a.B; pr += 256) {
+        const int s = pr / a.B, b = pr - s * a.B;
+        float sum = 0.f;
+        for (int k = 0; k < DM_CHUNKS; ++k) sum += a.means[s][(size_t)b * DM_CHUNKS + k];
+        s_mean[pr] = sum / (float)((a.H >> s) * (a.W >> s));
+    }
+    __syncthreads();
     for (int pr = tid; pr < 4 * a.B; pr += 256) {
         const int s = pr / a.B, b = pr - s * a.B;
         float sum = 0.f;
@@ -148,7 +160,7 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(FinalizeArgs a) {
         const int by = i / ((h - 1) * w), ry = i % ((h - 1) * w), yy = ry / w, xy = ry % w;
         const float* dxp = a.disp[s] + (size_t)bx * h * w;
         const float* dyp = a.disp[s] + (size_t)by * h * w;
-        const float mx = a.means[s][bx] + 1e-7f, my = a.means[s][by] + 1e-7f;
+        const float mx = s_mean[s * a.B + bx] + 1e-7f, my = s_mean[s * a.B + by] + 1e-7f;
         const float ax = dxp[yx * w + xx] / mx, bxv = dxp[yx * w + xx + 1] / mx;   // norm_disp (dpp.py:1087-1088)
         const float ay = dyp[yy * w + xy] / my, byv = dyp[(yy + 1) * w + xy] / my;
         float gix = 0.f, giy = 0.f;
@@ -191,7 +203,7 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(FinalizeArgs a) {
         for (int i = 0; i < a.n_smooth; ++i) { sm += s_sm[s * a.n_smooth + i]; dsum += s_ds[s * a.n_smooth + i]; }
         if (a.n_smooth > 0) {
             float* aux = a.smooth_aux + (size_t)s * (2 + 2 * a.n_smooth);
-            const float inv0 = 1.f / (a.means[s][0] + 1e-7f);
+            const float inv0 = 1.f / (s_mean[s * a.B + 0] + 1e-7f);
             aux[0] = inv0;
             aux[1] = dsum * inv0 * inv0 / (float)(h * w);   // mean-normalisation feedback term
         }
@@ -338,10 +350,12 @@ extern "C" int clslam_automask(const float* idmap, const float* noise, const flo
     return check_launch("automask");
 }
 
+extern "C" int clslam_disp_mean_chunks(void) { return DM_CHUNKS; }
+
 extern "C" int clslam_disp_mean(const float* disp, float* means, int batch, int hw, void* stream) {
     CLSLAM_REQUIRE(disp && means, "disp_mean: null");
     if (!batch) return CLSLAM_OK;
-    hipLaunchKernelGGL(disp_mean_kernel, dim3(batch), dim3(256), 0, (hipStream_t)stream, disp, means, hw);
+    hipLaunchKernelGGL(disp_mean_kernel, dim3(DM_CHUNKS, batch), dim3(256), 0, (hipStream_t)stream, disp, means, hw);
     return check_launch("disp_mean");
 }
 

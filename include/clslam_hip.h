@@ -165,12 +165,15 @@ int clslam_automask_blocks(int H, int W);
  * [id(-1)+noise, id(+1)+noise, reproj(-1), reproj(+1)]; partial [B][nblk] sums of the minimum.  */
 int clslam_automask(const float* idmap, const float* noise, const float* rpmap, unsigned char* sel, float* partial,
                     int batch, int H, int W, void* stream);
-int clslam_disp_mean(const float* disp, float* means, int batch, int hw, void* stream);
+/* psum [B][clslam_disp_mean_chunks()] partial sums of each sample's disparity map (the mean is
+ * formed inside clslam_loss_finalize).                                                            */
+int clslam_disp_mean_chunks(void);
+int clslam_disp_mean(const float* disp, float* psum, int batch, int hw, void* stream);
 typedef struct clslam_loss_desc {
     const float* partial[4];  /* automask partials per scale [B][nblk]                             */
     const float* disp[4];     /* ('disp',s) (B,H>>s,W>>s)                                          */
     const float* rgb0[4];     /* ('rgb',0,s) (B,3,H>>s,W>>s)                                       */
-    const float* means[4];    /* clslam_disp_mean outputs (B)                                      */
+    const float* means[4];    /* clslam_disp_mean outputs [B][chunks]                              */
     const float* pose;        /* (2B,12)                                                           */
     const double* dist0;      /* ('relative_distance',0) (B) float64                               */
     const double* dist1;

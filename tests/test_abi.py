@@ -2,6 +2,8 @@
 (no compute call without a GPU)."""
 import ctypes
 import re
+
+import torch  # noqa: F401  (before the library: same HIP runtime)
 import sys
 from pathlib import Path
 

@@ -33,7 +33,7 @@ def _run_loss_stage(dev, inputs, disp, pose, noise, sample_w, smooth_w, H, W, mi
     nblk = ops.automask_blocks(H, W)
     partial = torch.empty(4, B, nblk, device=dev)
     sel = torch.empty(4, B, H, W, dtype=torch.uint8, device=dev)
-    means = torch.empty(4, B, device=dev)
+    means = torch.empty(4, B, ops.disp_mean_chunks(), device=dev)
     for s in range(4):
         ops.photo_map(warped[s], src[0], rpmap[s], coef[s] if train else None, 2 * B, B, H, W)
         ops.automask(idmap, t(noise[s]) if noise is not None else None, rpmap[s], sel[s], partial[s], B, H, W)
