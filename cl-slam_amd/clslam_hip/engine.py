@@ -440,7 +440,10 @@ class Engine:
 
     # ------------------------------------------------------------------------------------------
     # backward
-    def _wgrad(self, t, desc_src, out_shape, dz, name_prefix: str, cout: int, cin: int, taps: int, **geom) -> None:
+    def _wgrad(self, t, desc_src, out_shape, dz, name_prefix: str, cout: int, cin: int, taps: int, bias_blocks: int = 0,
+               **geom) -> None:
+        """weight (+ bias) gradient of one conv into the gradient arena; bias_blocks > 0 means
+        t.colsum already holds that many per-block column sums of dz (fused into fold_act_grad)."""
         desc = ops.conv_desc(desc_src[0], out_shape, src_b=desc_src[1], ksize=3 if taps == 9 else 1, **geom)
         splits = ops.wgrad_splits(desc, 1024)
         n = cout * taps * cin
@@ -449,6 +452,9 @@ class Engine:
             t.partial = torch.empty(t.partial_elems, device=self.device)
         ops.conv_wgrad(desc, dz, t.partial, splits)
         ops.reduce_partials(t.partial, self._slot(self.g, name_prefix + '.weight', n), n, splits)
+        if bias_blocks:
+            ops.reduce_partials(t.colsum, self._slot(self.g, name_prefix + '.bias', cout), cout, bias_blocks)
+            return
         rows = out_shape[0] * out_shape[1] * out_shape[2]
         nb = ops.colsum_blocks(rows)
         ops.colsum(dz, t.colsum, rows, cout)
@@ -484,24 +490,28 @@ class Engine:
                 ops.dispconv_wgrad(t.dz_disp[i], ws.x[i, 1], t.disp_part)
                 ops.reduce_partials(t.disp_part, self._slot(self.g, f'depth_decoder/dispconv_{i}.conv.weight', 9 * ci + 1),
                                     9 * ci + 1, nb)
-            ops.fold_act_grad(dxp_in, ws.x[i, 1], t.dz[i, 1], h=hi, w=wi, ch=ci, border=1, pool=False, act=ACT_ELU)
+            nb1 = ops.fold_blocks(B, hi, wi, ci, False)
+            ops.fold_act_grad(dxp_in, ws.x[i, 1], t.dz[i, 1], h=hi, w=wi, ch=ci, border=1, pool=False, act=ACT_ELU,
+                              bias_partial=t.colsum)
             # upconv_i_1: input = cat(up(x[i,0]), feats[i-1])
             skip = feats[i - 1] if i > 0 else None
             cin1 = ci + (NUM_CH_ENC[i - 1] if i > 0 else 0)
             self._wgrad(t, (ws.x[i, 0], skip), (B, hi, wi, ci), t.dz[i, 1], f'depth_decoder/upconv_{i}_1.conv.conv', ci, cin1, 9,
-                        pad_mode=PAD_REFLECT, upsample_a=True)
+                        bias_blocks=nb1, pad_mode=PAD_REFLECT, upsample_a=True)
             w1, _ = self._wb(f'depth_decoder/upconv_{i}_1.conv.conv', ci, cin1, 9)
             wt = t.wt[:ci * 9 * ci].view(ci, 9, ci)
             ops.weight_transpose(w1, wt, ch_in_sel=ci)          # only the up(x[i,0]) half: the skip half is frozen
             dxa = t.dxp[1][:B * (hi + 2) * (wi + 2) * ci].view(B, hi + 2, wi + 2, ci)
             ops.conv2d(t.dz[i, 1], wt, dxa, ksize=3, pad=2)
-            ops.fold_act_grad(dxa, ws.x[i, 0], t.dz[i, 0], h=hi, w=wi, ch=ci, border=1, pool=True, act=ACT_ELU)
+            nb0 = ops.fold_blocks(B, hi, wi, ci, True)
+            ops.fold_act_grad(dxa, ws.x[i, 0], t.dz[i, 0], h=hi, w=wi, ch=ci, border=1, pool=True, act=ACT_ELU,
+                              bias_partial=t.colsum)
             # upconv_i_0: input = x[i+1,1] (or the frozen encoder feature for i == 4)
             src = ws.x[i + 1, 1] if i < 4 else feats[4]
             cin0 = NUM_CH_ENC[-1] if i == 4 else NUM_CH_DEC[i + 1]
             h2, w2 = hi >> 1, wi >> 1
             self._wgrad(t, (src, None), (B, h2, w2, ci), t.dz[i, 0], f'depth_decoder/upconv_{i}_0.conv.conv', ci, cin0, 9,
-                        pad_mode=PAD_REFLECT)
+                        bias_blocks=nb0, pad_mode=PAD_REFLECT)
             if i < 4:
                 w0, _ = self._wb(f'depth_decoder/upconv_{i}_0.conv.conv', ci, cin0, 9)
                 wt = t.wt[:cin0 * 9 * ci].view(cin0, 9, ci)

@@ -86,10 +86,14 @@ def weight_transpose(w, wt, ch_in_sel=None):
     return wt
 
 
-def fold_act_grad(dxp, yout, dz, *, h, w, ch, border, pool, act):
+def fold_blocks(batch, h, w, ch, pool) -> int:
+    return _lib.get_lib().cdll.clslam_fold_blocks(batch, h, w, ch, int(pool))
+
+
+def fold_act_grad(dxp, yout, dz, *, h, w, ch, border, pool, act, bias_partial=None):
     B = dxp.shape[0]
-    _lib.get_lib().call('clslam_fold_act_grad', _p(dxp), _p(yout), _p(dz), B, h, w, ch, dxp.shape[3], border,
-                        int(pool), act, _stream(dz))
+    _lib.get_lib().call('clslam_fold_act_grad', _p(dxp), _p(yout), _p(dz), _p(bias_partial), B, h, w, ch, dxp.shape[3],
+                        border, int(pool), act, _stream(dz))
     return dz
 
 

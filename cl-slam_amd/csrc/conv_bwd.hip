@@ -29,9 +29,13 @@ __global__ void weight_transpose_kernel(const float* __restrict__ w, float* __re
 
 // ------------------------------------------------------------------------------------------------
 // dz[b,y,x,c] = act'(yout[b,y,x,c]) * sum_{(Y,X) in footprint(y,x)} sum_{P -> (Y,X)} dxp[b,P,c]
-__global__ void fold_act_grad_kernel(const float* __restrict__ dxp, const float* __restrict__ yout,
-                                     float* __restrict__ dz, int B, int H, int W, int C, int e, int pool,
-                                     int act, int Cp) {
+__global__ __launch_bounds__(256) void fold_act_grad_kernel(const float* __restrict__ dxp, const float* __restrict__ yout,
+                                                            float* __restrict__ dz, float* __restrict__ bias_partial, int B,
+                                                            int H, int W, int C, int e, int pool, int act, int Cp) {
+    // bias_partial (optional): [gridDim.x][C] per-block column sums of dz = the conv's bias gradient
+    // partials (C/4 divides 256 and the grid stride, so a thread keeps one channel quad throughout).
+    __shared__ float4 bred[256];
+    float4 bacc = make_float4(0.f, 0.f, 0.f, 0.f);
     // H, W: resolution of the conv input whose padded-domain gradient dxp [(H+2e)][(W+2e)][Cp] holds;
     // output resolution is (H,W) or (H/2,W/2) when pool; only channels [0,C) are consumed.
     const int Ho = pool ? H / 2 : H, Wo = pool ? W / 2 : W;
@@ -75,6 +79,16 @@ __global__ void fold_act_grad_kernel(const float* __restrict__ dxp, const float*
             acc.w *= act_grad_from_output(yv.w, act);
         }
         *reinterpret_cast<float4*>(dz + o) = acc;
+        bacc.x += acc.x; bacc.y += acc.y; bacc.z += acc.z; bacc.w += acc.w;
+    }
+    if (bias_partial) {
+        bred[threadIdx.x] = bacc;
+        __syncthreads();
+        if ((int)threadIdx.x < C4) {
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int k = threadIdx.x; k < 256; k += C4) { const float4 v = bred[k]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+            *reinterpret_cast<float4*>(bias_partial + (size_t)blockIdx.x * C + threadIdx.x * 4) = t;
+        }
     }
 }
 
@@ -299,16 +313,22 @@ extern "C" int clslam_weight_transpose(const float* w, float* wt, int ch_out, in
     return check_launch("weight_transpose");
 }
 
-extern "C" int clslam_fold_act_grad(const float* dxp, const float* yout, float* dz, int batch, int h, int w, int ch,
-                                    int ch_stride, int border, int pool, int act, void* stream) {
+extern "C" int clslam_fold_blocks(int batch, int h, int w, int ch, int pool) {
+    const size_t total = (size_t)batch * (pool ? h / 2 : h) * (pool ? w / 2 : w) * (ch / 4);
+    return (int)std::max<size_t>(1, std::min<size_t>(1024, (total + 255) / 256));
+}
+
+extern "C" int clslam_fold_act_grad(const float* dxp, const float* yout, float* dz, float* bias_partial, int batch, int h,
+                                    int w, int ch, int ch_stride, int border, int pool, int act, void* stream) {
     CLSLAM_REQUIRE(dxp && dz && ch % 4 == 0 && ch_stride % 4 == 0 && ch <= ch_stride, "fold_act_grad: bad args");
     CLSLAM_REQUIRE(border == 0 || border == 1, "fold_act_grad: border must be 0/1");
     CLSLAM_REQUIRE(!pool || (h % 2 == 0 && w % 2 == 0), "fold_act_grad: pooling needs even dims");
     const size_t total = (size_t)batch * (pool ? h / 2 : h) * (pool ? w / 2 : w) * (ch / 4);
     if (total == 0) return CLSLAM_OK;
-    const int blocks = (int)std::min<size_t>(4096, (total + 255) / 256);
-    hipLaunchKernelGGL(fold_act_grad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dxp, yout, dz, batch, h, w,
-                       ch, border, pool, act, ch_stride);
+    CLSLAM_REQUIRE(!bias_partial || (256 % (ch / 4) == 0), "fold_act_grad: fused bias sums need ch/4 to divide 256");
+    const int blocks = clslam_fold_blocks(batch, h, w, ch, pool);
+    hipLaunchKernelGGL(fold_act_grad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dxp, yout, dz, bias_partial, batch,
+                       h, w, ch, border, pool, act, ch_stride);
     return check_launch("fold_act_grad");
 }
 

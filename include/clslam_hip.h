@@ -87,8 +87,11 @@ int clslam_weight_transpose(const float* w, float* wt, int ch_out, int taps, int
  * (ReflectionPad2d backward), pool=1 sums each 2x2 block (nearest-2x upsample backward, output
  * is [B][h/2][w/2][ch]); only channels [0,ch) are used (the skip half of a concat is dead:
  * encoders are frozen, dpp.py:308,813-819); yout may be NULL (no activation).                 */
-int clslam_fold_act_grad(const float* dxp, const float* yout, float* dz, int batch, int h, int w, int ch,
-                         int ch_stride, int border, int pool, int act, void* stream);
+/* bias_partial (optional) receives [clslam_fold_blocks(...)][ch] per-block column sums of dz, i.e.
+ * the bias-gradient partials of the conv that produced yout (reduce with clslam_reduce_partials). */
+int clslam_fold_blocks(int batch, int h, int w, int ch, int pool);
+int clslam_fold_act_grad(const float* dxp, const float* yout, float* dz, float* bias_partial, int batch, int h, int w,
+                         int ch, int ch_stride, int border, int pool, int act, void* stream);
 /* Weight gradient as an MFMA GEMM reducing over pixels; desc = the forward conv's descriptor. */
 int clslam_wgrad_splits(const clslam_conv_desc* desc, int target_blocks);
 int clslam_conv_wgrad(const clslam_conv_desc* desc, const float* dz, float* partial, int splits, void* stream);

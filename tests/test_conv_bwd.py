@@ -86,7 +86,12 @@ def test_conv_backward_matches_autograd(case, backend):
         dxp = torch.full((B, H + 2, W + 2, Ca), float('nan'), device=dev)
         ops.conv2d(dz_d, wt.view(Ca, taps, Cout), dxp, ksize=3, pad=2)
         dpre = torch.empty(B, Ha, Wa, Ca, device=dev)
-        ops.fold_act_grad(dxp, xa_d, dpre, h=H, w=W, ch=Ca, border=1, pool=ups, act=act)
+        nbf = ops.fold_blocks(B, H, W, Ca, ups)
+        bpart = torch.full((nbf * Ca,), float('nan'), device=dev)
+        ops.fold_act_grad(dxp, xa_d, dpre, h=H, w=W, ch=Ca, border=1, pool=ups, act=act, bias_partial=bpart)
+        bsum = torch.empty(Ca, device=dev)
+        ops.reduce_partials(bpart, bsum, Ca, nbf)       # fused column sums == bias gradient of the producer conv
+        assert rel_err(bsum.cpu(), dpre.cpu().sum((0, 1, 2))) < 1e-5
     else:
         dpre = torch.full((B, H, W, Ca), float('nan'), device=dev)
         ops.conv2d(dz_d, wt.view(Ca, taps, Cout), dpre, ksize=k, pad=k // 2, actgrad_src=xa_d, actgrad_kind=act)
