@@ -146,9 +146,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradK p) {
             const int f = tid + it * 256;
             const int row = f / (COT / 4), c4 = f % (COT / 4);
             const int m = mc + row;
-            rz[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (f < Z_F4 && m < mend)
-                rz[it] = *reinterpret_cast<const float4*>(p.dz + (size_t)m * p.Cout + co0 + c4 * 4);
+            const bool okz = (f < Z_F4) && (m < mend);
+            rz[it] = *reinterpret_cast<const float4*>(p.dz + (size_t)(okz ? m : 0) * p.Cout + co0 + (okz ? c4 * 4 : 0));
+            if (!okz) rz[it] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int it = 0; it < G_IT; ++it) {
@@ -173,17 +173,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradK p) {
                 } else {
                     ok = ok && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
                 }
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (ok) {
-                    const float* ptr;
-                    if (c < p.Ca) {
-                        const int sy = p.ups ? (iy >> 1) : iy, sx = p.ups ? (ix >> 1) : ix;
-                        ptr = p.src_a + ((size_t)(b * HA + sy) * WA + sx) * p.Ca + c;
-                    } else {
-                        ptr = p.src_b + ((size_t)(b * p.Hi + iy) * p.Wi + ix) * p.Cb + (c - p.Ca);
-                    }
-                    v = *reinterpret_cast<const float4*>(ptr);
-                }
+                const int sy = p.ups ? (iy >> 1) : iy, sx = p.ups ? (ix >> 1) : ix;
+                const size_t oa = ok ? ((size_t)(b * HA + sy) * WA + sx) * p.Ca : 0;
+                const size_t ob = ok ? ((size_t)(b * p.Hi + iy) * p.Wi + ix) * p.Cb : 0;
+                const float* ptr = (c < p.Ca) ? p.src_a + oa + c : p.src_b + ob + (c - p.Ca);
+                float4 v = *reinterpret_cast<const float4*>(ptr);   // unconditional, masked below
+                if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
                 rg[t][it] = v;
             }
         }

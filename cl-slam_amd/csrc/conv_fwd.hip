@@ -105,17 +105,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvK p) {
             } else {
                 ok = ok && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
             }
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ok) {
-                const float* ptr;
-                if (c < p.Ca) {
-                    const int sy = p.ups ? (iy >> 1) : iy, sx = p.ups ? (ix >> 1) : ix;
-                    ptr = p.src_a + ((size_t)(a_b[it] * HA + sy) * WA + sx) * p.Ca + c;
-                } else {
-                    ptr = p.src_b + ((size_t)(a_b[it] * p.Hi + iy) * p.Wi + ix) * p.Cb + (c - p.Ca);
-                }
-                v = *reinterpret_cast<const float4*>(ptr);
-            }
+            // unconditional load from a valid address, masked afterwards: a branch around the load would
+            // make the compiler wait vmcnt(0) at the join and serialise the prefetch
+            const int sy = p.ups ? (iy >> 1) : iy, sx = p.ups ? (ix >> 1) : ix;
+            const size_t oa = ok ? ((size_t)(a_b[it] * HA + sy) * WA + sx) * p.Ca : 0;
+            const size_t ob = ok ? ((size_t)(a_b[it] * p.Hi + iy) * p.Wi + ix) * p.Cb : 0;
+            const float* ptr = (c < p.Ca) ? p.src_a + oa + c : p.src_b + ob + (c - p.Ca);
+            float4 v = *reinterpret_cast<const float4*>(ptr);
+            if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
             ra[it] = v;
         }
 #pragma unroll
@@ -123,9 +120,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvK p) {
             const int f = tid + it * 256;
             const int row = f / F4_ROW;
             const int n = n0 + row;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (f < BN * F4_ROW && n < p.Cout)
-                v = *reinterpret_cast<const float4*>(p.wgt + ((size_t)n * taps + tap) * Cin + c0 + (f % F4_ROW) * 4);
+            const bool okb = (f < BN * F4_ROW) && (n < p.Cout);
+            float4 v = *reinterpret_cast<const float4*>(p.wgt + ((size_t)(okb ? n : 0) * taps + tap) * Cin + c0 + (f % F4_ROW) * 4);
+            if (!okb) v = make_float4(0.f, 0.f, 0.f, 0.f);
             rb[it] = v;
         }
     };
@@ -227,6 +224,8 @@ static int launch_conv(ConvK k, hipStream_t stream) {
 
 }  // namespace clslam
 
+namespace clslam { int conv3x3_patch_dispatch(const clslam_conv_desc* d, int cfg, hipStream_t stream); }
+
 using namespace clslam;
 
 // Tile configurations (BM x BN x BK, MFMA shape, wave grid).  Chosen per layer by clslam_conv2d
@@ -238,6 +237,7 @@ using namespace clslam;
 //   4: 128x16x16  16x16x4  4x1 (2x1 tiles/wave)          Cout == 16, Cin % 32 != 0
 //   5:  64x32x16  16x16x4  2x2                           BK = 16 fallback
 //   6: 128x16x32  16x16x4  4x1                           Cout == 16, Cin % 32 == 0
+//  10-13: LDS-patch kernel for 3x3 stride-1 convs (conv_patch.hip): 8x16 px x {64,32,16} ch, 4x16 px x 64 ch
 extern "C" int clslam_conv2d_pick_config(const clslam_conv_desc* d) {
     const int Cin = d->ch_a + d->ch_b;
     const int M = d->batch * d->out_h * d->out_w;
@@ -274,6 +274,7 @@ extern "C" int clslam_conv2d(const clslam_conv_desc* d, void* stream_) {
     int cfg = d->config;
     const bool bk32 = (Cin % 32 == 0) && (d->ch_b == 0 || d->ch_a % 32 == 0);
     if (cfg < 0) cfg = clslam_conv2d_pick_config(d);
+    if (cfg >= 10) return conv3x3_patch_dispatch(d, cfg, stream);
     const bool need32 = (cfg <= 3 || cfg == 6);
     if (need32 && !bk32) { set_error("conv2d: config %d needs channel multiples of 32", cfg); return CLSLAM_ERR_INVALID; }
     if ((cfg == 0 || cfg == 1) && d->ch_out % 32 != 0) { set_error("conv2d: config %d needs Cout %% 32 == 0", cfg); return CLSLAM_ERR_INVALID; }

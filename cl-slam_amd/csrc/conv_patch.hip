@@ -1,0 +1,243 @@
+// K3/K5 v2: 3x3 stride-1 convolution with an LDS-resident input patch.
+//
+// conv_fwd.hip re-reads its A tile from L2 for each of the 9 taps (arithmetic intensity ~8 flop/B
+// from L2 for a 32x32 tile), which measured 40-70 TFLOP/s on MI355X: L2-bandwidth/latency bound.
+// Here a block owns a TH x TW output tile of ONE image and BN output channels.  Per chunk of BK input
+// channels it stages ONCE in LDS
+//     * the (TH+2) x (TW+2) x BK input patch (halo x1.4 instead of x9; zero/reflect padding, nearest-2x
+//       upsampling and skip-concat are resolved while filling it, exactly as in conv_fwd.hip), and
+//     * the 9 x BN x BK weight slab,
+// and runs all 9 taps x BK/4 MFMA k-steps out of LDS: ~48 flop per byte fetched from L2 for the
+// 8x16x64 configuration.  The next chunk is prefetched global->registers while the MFMAs of the current
+// chunk run; rows are padded to BK+4 floats so the ds_read_b128 fragment reads of neighbouring pixels
+// fall on distinct 16-byte bank slots.  Same operand convention as conv_fwd.hip (lane's float4 = four
+// consecutive k-steps), same fused epilogue.  Used for every stride-1 3x3 conv whose image is large
+// enough to tile (forward, and dgrad on the padded domain with pad = 2).
+#include "common.h"
+
+namespace clslam {
+
+struct PatchK {
+    const float* __restrict__ src_a;
+    const float* __restrict__ src_b;
+    const float* __restrict__ wgt;
+    const float* __restrict__ scale;
+    const float* __restrict__ shift;
+    const float* __restrict__ residual;
+    const float* __restrict__ actgrad_src;
+    float* __restrict__ out;
+    int actgrad_kind;
+    int B, Hi, Wi, Ca, Cb, Ho, Wo, Cout;
+    int pad, pad_mode, ups, act;
+    int tilesX, tilesY, tilesN, nblk;
+};
+
+template <int TH, int TW, int BN, int BK, int MF, int WGM>
+__global__ __launch_bounds__(256) void conv3x3_patch_kernel(PatchK p) {
+    constexpr int BM = TH * TW;
+    constexpr int PH = TH + 2, PW = TW + 2, PP = PH * PW;
+    constexpr int LD = BK + 4;
+    constexpr int WGN = 4 / WGM;
+    constexpr int WM = BM / WGM, WN = BN / WGN;
+    constexpr int TM = WM / MF, TN = WN / MF;
+    constexpr int KG = 64 / MF, KSTEP = KG * 4;
+    constexpr int F4 = BK / 4;
+    constexpr int P_SLOTS = PP * F4, W_SLOTS = 9 * BN * F4;
+    constexpr int P_IT = (P_SLOTS + 255) / 256, W_IT = (W_SLOTS + 255) / 256;
+    constexpr int NACC = MF == 32 ? 16 : 4;
+    static_assert(WM % MF == 0 && WN % MF == 0 && BK % KSTEP == 0 && TW % 16 == 0, "tile shape");
+
+    __shared__ __attribute__((aligned(16))) float Ps[PP * LD];
+    __shared__ __attribute__((aligned(16))) float Wsm[9 * BN * LD];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm0 = (wave / WGN) * WM, wn0 = (wave % WGN) * WN;
+
+    int logical = xcd_remap((int)blockIdx.x, p.nblk);
+    const int tx = logical % p.tilesX; logical /= p.tilesX;
+    const int ty = logical % p.tilesY; logical /= p.tilesY;
+    const int b = logical % p.B;
+    const int tn = logical / p.B;
+    const int oy0 = ty * TH, ox0 = tx * TW, n0 = tn * BN;
+    const int Cin = p.Ca + p.Cb;
+    const int HA = p.ups ? (p.Hi >> 1) : p.Hi, WA = p.ups ? (p.Wi >> 1) : p.Wi;
+
+    // ---- per-thread patch slots: element offsets of the source pixel in src_a / src_b (-1: zero) ----
+    int offA[P_IT], offB[P_IT];
+#pragma unroll
+    for (int it = 0; it < P_IT; ++it) {
+        const int f = tid + it * 256;
+        const int pp = f / F4;
+        offA[it] = -1; offB[it] = -1;
+        if (f < P_SLOTS) {
+            const int pr = pp / PW, pc = pp - pr * PW;
+            int iy = oy0 - p.pad + pr, ix = ox0 - p.pad + pc;
+            bool ok = true;
+            if (p.pad_mode == CLSLAM_PAD_REFLECT) {
+                iy = reflect_idx(iy, p.Hi); ix = reflect_idx(ix, p.Wi);
+                iy = min(max(iy, 0), p.Hi - 1); ix = min(max(ix, 0), p.Wi - 1);   // overhanging tiles
+            } else {
+                ok = iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
+            }
+            if (ok) {
+                const int sy = p.ups ? (iy >> 1) : iy, sx = p.ups ? (ix >> 1) : ix;
+                offA[it] = ((b * HA + sy) * WA + sx) * p.Ca;
+                offB[it] = ((b * p.Hi + iy) * p.Wi + ix) * p.Cb;
+            }
+        }
+    }
+
+    float4 rp[P_IT], rw[W_IT];
+    auto load_global = [&](int c0) {
+#pragma unroll
+        for (int it = 0; it < P_IT; ++it) {
+            const int f = tid + it * 256;
+            const int c = c0 + (f % F4) * 4;
+            // unconditional load from a valid address, masked afterwards (no branch around the load)
+            const bool fromA = c < p.Ca;
+            const bool ok = offA[it] >= 0;
+            const float* ptr = fromA ? p.src_a + (ok ? offA[it] : 0) + c : p.src_b + (ok ? offB[it] : 0) + (c - p.Ca);
+            float4 v = *reinterpret_cast<const float4*>(ptr);
+            if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            rp[it] = v;
+        }
+#pragma unroll
+        for (int it = 0; it < W_IT; ++it) {
+            const int f = tid + it * 256;
+            const int c4 = f % F4;
+            const int n = (f / F4) % BN;
+            const int tap = f / (F4 * BN);
+            const bool ok = (f < W_SLOTS) && (n0 + n < p.Cout);
+            const float* ptr = p.wgt + ((size_t)(ok ? n0 + n : 0) * 9 + (ok ? tap : 0)) * Cin + c0 + c4 * 4;
+            float4 v = *reinterpret_cast<const float4*>(ptr);
+            if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            rw[it] = v;
+        }
+    };
+    auto store_lds = [&]() {
+#pragma unroll
+        for (int it = 0; it < P_IT; ++it) {
+            const int f = tid + it * 256;
+            if (f < P_SLOTS) *reinterpret_cast<float4*>(&Ps[(f / F4) * LD + (f % F4) * 4]) = rp[it];
+        }
+#pragma unroll
+        for (int it = 0; it < W_IT; ++it) {
+            const int f = tid + it * 256;
+            if (f < W_SLOTS) *reinterpret_cast<float4*>(&Wsm[(f / F4) * LD + (f % F4) * 4]) = rw[it];
+        }
+    };
+
+    typedef float accv __attribute__((ext_vector_type(NACC)));
+    accv acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < NACC; ++r) acc[i][j][r] = 0.f;
+
+    const int frow = lane % MF, kg = lane / MF;
+    // LDS row of this lane's pixel for tap (0,0), per M tile
+    int prow[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = wm0 + i * MF + frow;
+        prow[i] = (m / TW) * PW + (m % TW);
+    }
+
+    load_global(0);
+    for (int c0 = 0; c0 < Cin; c0 += BK) {
+        __syncthreads();           // previous chunk's MFMAs are done with LDS
+        store_lds();
+        __syncthreads();
+        if (c0 + BK < Cin) load_global(c0 + BK);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+            for (int kk = 0; kk < BK / KSTEP; ++kk) {
+                float4 fa[TM], fb[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    fa[i] = *reinterpret_cast<const float4*>(&Ps[(prow[i] + ky * PW + kx) * LD + kk * KSTEP + kg * 4]);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    fb[j] = *reinterpret_cast<const float4*>(&Wsm[((tap * BN) + wn0 + j * MF + frow) * LD + kk * KSTEP + kg * 4]);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        const float av = t == 0 ? fa[i].x : t == 1 ? fa[i].y : t == 2 ? fa[i].z : fa[i].w;
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) {
+                            const float bv = t == 0 ? fb[j].x : t == 1 ? fb[j].y : t == 2 ? fb[j].z : fb[j].w;
+                            if constexpr (MF == 32) acc[i][j] = mfma_32x32x2(av, bv, acc[i][j]);
+                            else acc[i][j] = mfma_16x16x4(av, bv, acc[i][j]);
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- epilogue --------------------------------------------------------------------------------
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn0 + j * MF + (lane % MF);
+            if (n >= p.Cout) continue;
+            const float sc = p.scale ? p.scale[n] : 1.f;
+            const float sh = p.shift ? p.shift[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < NACC; ++r) {
+                int row;
+                if constexpr (MF == 32) row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                else row = 4 * (lane >> 4) + r;
+                const int m = wm0 + i * MF + row;
+                const int oy = oy0 + m / TW, ox = ox0 + m % TW;
+                if (oy >= p.Ho || ox >= p.Wo) continue;
+                const size_t o = (((size_t)b * p.Ho + oy) * p.Wo + ox) * p.Cout + n;
+                float v = acc[i][j][r] * sc + sh;
+                if (p.residual) v += p.residual[o];
+                v = apply_act(v, p.act);
+                if (p.actgrad_src) v *= act_grad_from_output(p.actgrad_src[o], p.actgrad_kind);
+                p.out[o] = v;
+            }
+        }
+    }
+}
+
+template <int TH, int TW, int BN, int BK, int MF, int WGM>
+static int launch_patch(PatchK k, hipStream_t stream) {
+    k.tilesX = cdiv(k.Wo, TW);
+    k.tilesY = cdiv(k.Ho, TH);
+    k.tilesN = cdiv(k.Cout, BN);
+    k.nblk = k.tilesX * k.tilesY * k.tilesN * k.B;
+    hipLaunchKernelGGL((conv3x3_patch_kernel<TH, TW, BN, BK, MF, WGM>), dim3(k.nblk), dim3(256), 0, stream, k);
+    return check_launch("conv3x3_patch");
+}
+
+// Called by clslam_conv2d for configs >= 10.
+int conv3x3_patch_dispatch(const clslam_conv_desc* d, int cfg, hipStream_t stream) {
+    if (d->ksize != 3 || d->stride != 1) { set_error("conv2d: patch configs need a 3x3 stride-1 conv"); return CLSLAM_ERR_INVALID; }
+    if (d->out_h != d->in_h + 2 * d->pad - 2 || d->out_w != d->in_w + 2 * d->pad - 2) {
+        set_error("conv2d: inconsistent output size for the patch kernel");
+        return CLSLAM_ERR_INVALID;
+    }
+    PatchK k;
+    k.src_a = d->src_a; k.src_b = d->src_b; k.wgt = d->weight; k.scale = d->scale; k.shift = d->shift;
+    k.residual = d->residual; k.actgrad_src = d->actgrad_src; k.out = d->out; k.actgrad_kind = d->actgrad_kind;
+    k.B = d->batch; k.Hi = d->in_h; k.Wi = d->in_w; k.Ca = d->ch_a; k.Cb = d->ch_b; k.Ho = d->out_h; k.Wo = d->out_w;
+    k.Cout = d->ch_out; k.pad = d->pad; k.pad_mode = d->pad_mode; k.ups = d->upsample_a; k.act = d->act;
+    k.tilesX = k.tilesY = k.tilesN = k.nblk = 0;
+    switch (cfg) {
+        case 10: return launch_patch<8, 16, 64, 16, 32, 2>(k, stream);   // 128 px x 64 ch, 32x32x2
+        case 11: return launch_patch<8, 16, 32, 16, 32, 4>(k, stream);   // 128 px x 32 ch
+        case 12: return launch_patch<8, 16, 16, 16, 16, 4>(k, stream);   // 128 px x 16 ch, 16x16x4
+        case 13: return launch_patch<4, 16, 64, 16, 32, 2>(k, stream);   //  64 px x 64 ch
+        default: set_error("conv2d: unknown patch config %d", cfg); return CLSLAM_ERR_INVALID;
+    }
+}
+
+}  // namespace clslam

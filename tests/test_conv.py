@@ -43,6 +43,13 @@ CASES = [
     (3, 12, 20, 64, 0, 64, 3, 1, 0, False, 1, True, 0),
     (1, 4, 6, 16, 0, 32, 3, 1, 0, False, 0, False, 5),
     (2, 6, 20, 64, 0, 128, 3, 1, 0, False, 1, False, -1),
+    # LDS-patch kernel (configs 10-13): ragged tiles, reflect/zero, upsample + concat, residual
+    (2, 12, 20, 32, 0, 64, 3, 1, 0, False, 1, True, 10),
+    (1, 10, 36, 64, 64, 64, 3, 1, 1, True, 2, False, 10),
+    (1, 8, 16, 32, 64, 32, 3, 1, 1, True, 2, False, 11),
+    (2, 9, 18, 16, 0, 16, 3, 1, 1, False, 2, False, 12),
+    (1, 12, 40, 16, 0, 16, 3, 1, 1, True, 2, False, 12),
+    (3, 6, 20, 48, 0, 128, 3, 1, 0, False, 1, True, 13),
 ]
 
 

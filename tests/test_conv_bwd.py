@@ -85,6 +85,10 @@ def test_conv_backward_matches_autograd(case, backend):
     if k == 3 and reflect:
         dxp = torch.full((B, H + 2, W + 2, Ca), float('nan'), device=dev)
         ops.conv2d(dz_d, wt.view(Ca, taps, Cout), dxp, ksize=3, pad=2)
+        for pcfg in ((10, 13) if Ca % 64 == 0 else (11,) if Ca % 32 == 0 else (12,)):
+            dxp2 = torch.full_like(dxp, float('nan'))
+            ops.conv2d(dz_d, wt.view(Ca, taps, Cout), dxp2, ksize=3, pad=2, config=pcfg)
+            assert rel_err(dxp2.cpu(), dxp.cpu()) < 1e-5, pcfg
         dpre = torch.empty(B, Ha, Wa, Ca, device=dev)
         nbf = ops.fold_blocks(B, H, W, Ca, ups)
         bpart = torch.full((nbf * Ca,), float('nan'), device=dev)

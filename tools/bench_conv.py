@@ -26,6 +26,8 @@ LAYERS = [
     ('upconv_1_1 96->32 @96x320', 1, 96, 320, 32, 64, 32, 3, 1, 1, 1),
     ('upconv_0_0 32->16 @96x320', 1, 96, 320, 32, 0, 16, 3, 1, 1, 0),
     ('upconv_0_1 16->16 @192x640', 1, 192, 640, 16, 0, 16, 3, 1, 1, 1),
+    ('upconv_2_0 128->64 @24x80', 1, 24, 80, 128, 0, 64, 3, 1, 1, 0),
+    ('upconv_1_0 64->32 @48x160', 1, 48, 160, 64, 0, 32, 3, 1, 1, 0),
 ]
 
 
@@ -52,7 +54,7 @@ for name, bm, Hi, Wi, Ca, Cb, Cout, k, stride, refl, ups in LAYERS:
     out = torch.empty(Bn, Ho, Wo, Cout, device=dev)
     flops = 2.0 * Bn * Ho * Wo * Cout * k * k * (Ca + Cb)
     line = f'{name:32s} M={Bn*Ho*Wo:7d} {flops/1e9:7.2f} GF |'
-    cfgs = [-1, 0, 1, 2, 3, 4, 5, 6]
+    cfgs = [-1, 0, 1, 2, 3, 4, 5, 6, 10, 11, 12, 13]
     for cfg in cfgs:
         try:
             t = timeit(lambda: ops.conv2d(xa, w, out, src_b=xb, ksize=k, stride=stride, pad_mode=refl, upsample_a=bool(ups),
