@@ -154,14 +154,20 @@ def main():
             a[1] += e0.elapsed_time(e1) * 1e-3
             a[2] += 1
         ops.PROFILE = None
-        names = {0: '128x64x32/32x32x2', 1: '64x64x32/32x32x2', 2: '32x32x32/16x16x4', 3: '64x32x32/16x16x4',
-                 4: '128x16x16/16x16x4', 5: '64x32x16/16x16x4', 6: '128x16x32/16x16x4'}
+        names = {0: 'conv_igemm_kernel<128, 64, 32, 32, 2>', 1: 'conv_igemm_kernel<64, 64, 32, 32, 2>',
+                 2: 'conv_igemm_kernel<32, 32, 32, 16, 2>', 3: 'conv_igemm_kernel<64, 32, 32, 16, 2>',
+                 4: 'conv_igemm_kernel<128, 16, 16, 16, 4>', 5: 'conv_igemm_kernel<64, 32, 16, 16, 2>',
+                 6: 'conv_igemm_kernel<128, 16, 32, 16, 4>', 10: 'conv3x3_patch_kernel<8, 16, 64, 16, 32, 2>',
+                 11: 'conv3x3_patch_kernel<8, 16, 32, 16, 32, 4>', 12: 'conv3x3_patch_kernel<8, 16, 16, 16, 16, 4>',
+                 13: 'conv3x3_patch_kernel<4, 16, 64, 16, 32, 2>', 14: 'conv3x3_patch_kernel<8, 16, 16, 32, 16, 4>',
+                 15: 'conv3x3_patch_kernel<16, 16, 16, 16, 16, 4>', 16: 'conv3x3_patch_kernel<8, 16, 32, 16, 16, 4>',
+                 17: 'conv3x3_patch_kernel<4, 16, 16, 16, 16, 4>'}
         (kind, cfg), (fl, tt, cnt) = max(agg.items(), key=lambda kv: kv[1][1])
         all_fl = sum(a[0] for a in agg.values())
         all_t = sum(a[1] for a in agg.values())
         roof = {'bound': 'mfma', 'achieved': round(fl / tt / 1e12, 2), 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': round(fl / tt / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': None,
-                'kernel': f'conv_igemm_kernel<{names[cfg]}>', 'launches_per_step': cnt,
+                'kernel': names[cfg], 'launches_per_step': cnt,
                 'avg_launch_us': round(tt / cnt * 1e6, 2), 'flops_per_launch_avg': fl / cnt,
                 'all_conv_launches': {'achieved': round(all_fl / all_t / 1e12, 2), 'time_ms_per_step': round(all_t * 1e3, 3),
                                       'gflop_per_step': round(all_fl / 1e9, 2)}}

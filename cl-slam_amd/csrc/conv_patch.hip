@@ -236,6 +236,10 @@ int conv3x3_patch_dispatch(const clslam_conv_desc* d, int cfg, hipStream_t strea
         case 11: return launch_patch<8, 16, 32, 16, 32, 4>(k, stream);   // 128 px x 32 ch
         case 12: return launch_patch<8, 16, 16, 16, 16, 4>(k, stream);   // 128 px x 16 ch, 16x16x4
         case 13: return launch_patch<4, 16, 64, 16, 32, 2>(k, stream);   //  64 px x 64 ch
+        case 14: return launch_patch<8, 16, 16, 32, 16, 4>(k, stream);   // 128 px x 16 ch, BK = 32
+        case 15: return launch_patch<16, 16, 16, 16, 16, 4>(k, stream);  // 256 px x 16 ch
+        case 16: return launch_patch<8, 16, 32, 16, 16, 4>(k, stream);   // 128 px x 32 ch on 16x16x4
+        case 17: return launch_patch<4, 16, 16, 16, 16, 4>(k, stream);   //  64 px x 16 ch (small images)
         default: set_error("conv2d: unknown patch config %d", cfg); return CLSLAM_ERR_INVALID;
     }
 }

@@ -50,6 +50,10 @@ CASES = [
     (2, 9, 18, 16, 0, 16, 3, 1, 1, False, 2, False, 12),
     (1, 12, 40, 16, 0, 16, 3, 1, 1, True, 2, False, 12),
     (3, 6, 20, 48, 0, 128, 3, 1, 0, False, 1, True, 13),
+    (1, 9, 18, 32, 0, 16, 3, 1, 1, False, 2, False, 14),
+    (1, 18, 20, 16, 16, 16, 3, 1, 1, True, 2, False, 15),
+    (2, 9, 18, 16, 0, 32, 3, 1, 0, False, 1, True, 16),
+    (2, 6, 20, 32, 0, 48, 3, 1, 0, False, 1, False, 17),
 ]
 
 
