@@ -118,7 +118,7 @@ class Engine:
         self.models = None
         self._packed_version = None
         self._modules_stale = False
-        self.dist = None  # (process_group-like) set by enable_data_parallel
+        self.fresh_outputs = True
 
     # ------------------------------------------------------------------------------------------
     # parameters
@@ -273,7 +273,7 @@ class Engine:
         t.ddisp_up = E(B, H, W)
         t.nb2 = ops.warp_bwd_blocks(H, W)
         t.dp_partial = E(4, B, t.nb2, 24)
-        t.dz_disp = [torch.empty_like(d) for d in ws.disp]
+        t.dz_disp = [torch.empty(B, H >> s, W >> s, device=dev) for s in range(4)]
         t.dpose = E(2 * B, 12)
         t.dz = {k: torch.empty_like(v) for k, v in ws.x.items()}   # d(pre-ELU) of every upconv output
         pad_elems = max(B * ((H >> i) + 2) * ((W >> i) + 2) * NUM_CH_DEC[i] for i in range(5))
@@ -355,6 +355,13 @@ class Engine:
         ws = self.workspace(B)
         if train:
             self._train_bufs(ws)
+        if self.fresh_outputs:
+            # the reference returns fresh tensors from every call: the output planes are (cheap, cached)
+            # new allocations that the kernels write directly -- no copies
+            E = lambda *s: torch.empty(*s, device=self.device)  # noqa: E731
+            ws.disp = [E(B, H >> s, W >> s) for s in range(4)]
+            ws.pose, ws.T = E(2 * B, 12), E(2, B, 4, 4)
+            ws.depth, ws.warped, ws.losses = E(4, B, H, W), E(4, 2, B, 3, H, W), E(18)
         # networks ---------------------------------------------------------------------------
         dfeats = self._encoder(self.enc['depth_encoder'], ws.denc, B, [(aug[0], None, 0, B)])
         self._depth_decoder(ws, dfeats)

@@ -387,7 +387,7 @@ extern "C" int clslam_reduce_partials(const float* partial, float* out, size_t n
     return check_launch("reduce_partials");
 }
 
-extern "C" int clslam_colsum_blocks(int rows) { return std::max(1, std::min(512, cdiv(rows, 512))); }
+extern "C" int clslam_colsum_blocks(int rows) { return std::max(1, std::min(512, cdiv(rows, 16))); }
 
 // partial must hold clslam_colsum_blocks(rows)*ch floats; follow with clslam_reduce_partials.
 extern "C" int clslam_colsum(const float* x, float* partial, int rows, int ch, void* stream) {

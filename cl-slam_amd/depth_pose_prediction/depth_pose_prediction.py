@@ -215,7 +215,6 @@ class DepthPosePrediction:
 
         self._dp = None
         self._injected_noise = None
-        self.zero_copy_outputs = False
 
     # ============================================================
     # Data-parallel replay minibatch (new functionality; the reference has no multi-GPU adaptation)
@@ -426,13 +425,11 @@ class DepthPosePrediction:
                                               noise=self._injected_noise)
         if self._dp is not None:
             self._dp['dist'].all_reduce(losses, group=self._dp['group'])
-        loss_dict = self.engine.losses_dict(losses if self.zero_copy_outputs else losses.clone())
+        loss_dict = self.engine.losses_dict(losses)
         if np.isnan(loss_dict['loss'].item()):  # dpp.py:1115-1118 (also the step's only host sync)
             for k, v in loss_dict.items():
                 print(k, v.item())
             raise RuntimeError('NaN loss')
-        if not self.zero_copy_outputs:
-            outputs = {k: v.clone() for k, v in outputs.items()}
         return outputs, loss_dict
 
     def _backward(self, inputs: Dict[Any, Tensor]) -> None:
