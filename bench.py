@@ -88,6 +88,7 @@ def main():
     ap.add_argument('--height', type=int, default=192)
     ap.add_argument('--width', type=int, default=640)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--dump-convs', action='store_true', help='per-launch conv timings to stderr')
     args = ap.parse_args()
     H, W, N = args.height, args.width, args.gpus
 
@@ -148,7 +149,10 @@ def main():
         step()
         torch.cuda.synchronize()
         agg = {}
-        for kind, cfg, flops, e0, e1 in ops.PROFILE:
+        for kind, cfg, flops, e0, e1, desc in ops.PROFILE:
+            if args.dump_convs:
+                us = e0.elapsed_time(e1) * 1e3
+                print(f'# conv cfg{cfg:3d} {desc:40s} {flops / 1e9:7.2f} GF {us:8.1f} us {flops / us / 1e6:6.1f} TF', file=sys.stderr)
             a = agg.setdefault((kind, cfg), [0.0, 0.0, 0])
             a[0] += flops
             a[1] += e0.elapsed_time(e1) * 1e-3
@@ -158,10 +162,12 @@ def main():
                  2: 'conv_igemm_kernel<32, 32, 32, 16, 2>', 3: 'conv_igemm_kernel<64, 32, 32, 16, 2>',
                  4: 'conv_igemm_kernel<128, 16, 16, 16, 4>', 5: 'conv_igemm_kernel<64, 32, 16, 16, 2>',
                  6: 'conv_igemm_kernel<128, 16, 32, 16, 4>', 10: 'conv3x3_patch_kernel<8, 16, 64, 16, 32, 2>',
-                 11: 'conv3x3_patch_kernel<8, 16, 32, 16, 32, 4>', 12: 'conv3x3_patch_kernel<8, 16, 16, 16, 16, 4>',
+                 11: 'conv3x3_patch_kernel<8, 16, 32, 16, 32, 4>', 12: 'conv3x3_patch_kernel<8, 16, 16, 16, 16, 4, false, 4>',
                  13: 'conv3x3_patch_kernel<4, 16, 64, 16, 32, 2>', 14: 'conv3x3_patch_kernel<8, 16, 16, 32, 16, 4>',
                  15: 'conv3x3_patch_kernel<16, 16, 16, 16, 16, 4>', 16: 'conv3x3_patch_kernel<8, 16, 32, 16, 16, 4>',
-                 17: 'conv3x3_patch_kernel<4, 16, 16, 16, 16, 4>'}
+                 17: 'conv3x3_patch_kernel<4, 16, 16, 16, 16, 4, false, 4>', 18: 'conv3x3_patch_kernel<4, 16, 16, 16, 16, 4, true, 4>',
+                 19: 'conv3x3_patch_kernel<8, 16, 16, 16, 16, 4, true, 4>', 20: 'conv3x3_patch_kernel<8, 16, 16, 16, 16, 4, false, 8>',
+                 21: 'conv3x3_patch_kernel<4, 16, 16, 16, 16, 4, false, 8>', 22: 'conv3x3_patch_kernel<4, 16, 16, 16, 16, 4, true, 8>'}
         (kind, cfg), (fl, tt, cnt) = max(agg.items(), key=lambda kv: kv[1][1])
         all_fl = sum(a[0] for a in agg.values())
         all_t = sum(a[1] for a in agg.values())

@@ -59,7 +59,8 @@ def conv2d(src_a, weight, out, *, src_b=None, scale=None, shift=None, residual=N
         e0.record()
         _lib.get_lib().call('clslam_conv2d', C.byref(d), _stream(out))
         e1.record()
-        PROFILE.append(('conv_igemm', cfg, 2.0 * B * Ho * Wo * Cout * ksize * ksize * (Ca + Cb), e0, e1))
+        PROFILE.append(('conv_igemm', cfg, 2.0 * B * Ho * Wo * Cout * ksize * ksize * (Ca + Cb), e0, e1,
+                        f'B{B} {Hi}x{Wi} {Ca}+{Cb}->{Cout} k{ksize} s{stride} pad{pad}'))
         return out
     _lib.get_lib().call('clslam_conv2d', C.byref(d), _stream(out))
     return out

@@ -244,9 +244,10 @@ extern "C" int clslam_conv2d_pick_config(const clslam_conv_desc* d) {
     const bool bk32 = (Cin % 32 == 0) && (d->ch_b == 0 || d->ch_a % 32 == 0);
     // 3x3 stride-1: the LDS-patch kernel (conv_patch.hip).  Measured on MI355X (tools/bench_conv.py,
     // B=5 @192x640): 128 px x 16 ch tiles reach 80-104 TFLOP/s on the >= 48x160 layers, 64 px x 16 ch
-    // tiles 37-91 TFLOP/s on the smaller ones; both beat every conv_igemm tiling (26-67).
+    // tiles 65-95 TFLOP/s on the smaller ones, 64-px row-major runs 46-70 TFLOP/s on the 6x20 layers
+    // (a 4x16 rectangle wastes half its lanes there); all beat every conv_igemm tiling (26-67).
     if (d->ksize == 3 && d->stride == 1 && d->out_h == d->in_h + 2 * d->pad - 2 && d->out_w == d->in_w + 2 * d->pad - 2)
-        return M >= 30000 ? 12 : 17;
+        return d->out_w <= 24 ? 22 : (M >= 30000 ? 12 : 21);   // narrow images: run tiles
     if (d->ch_out % 32 != 0) return bk32 ? 6 : 4;
     if (!bk32) return 5;
     if (d->ch_out == 32) return 3;

@@ -32,11 +32,16 @@ struct PatchK {
     int tilesX, tilesY, tilesN, nblk;
 };
 
-template <int TH, int TW, int BN, int BK, int MF, int WGM>
+// RUN = true ("run tiles", for narrow images such as the 6x20 / 12x40 layers where a 4x16 rectangle
+// wastes half its lanes): the tile is a run of BM consecutive row-major output pixels of one image and
+// the patch is the full-width band of input rows it touches (runtime PH x (Wo+2), bounded by run_pp(BM)).
+constexpr int run_pp(int bm) { return bm <= 64 ? 224 : 320; }
+
+template <int TH, int TW, int BN, int BK, int MF, int WGM, bool RUN, int LDPAD>
 __global__ __launch_bounds__(256) void conv3x3_patch_kernel(PatchK p) {
     constexpr int BM = TH * TW;
-    constexpr int PH = TH + 2, PW = TW + 2, PP = PH * PW;
-    constexpr int LD = BK + 4;
+    constexpr int PH = TH + 2, PW = TW + 2, PP = RUN ? run_pp(BM) : PH * PW;
+    constexpr int LD = BK + LDPAD;   // +4: rows 16-B aligned; +8 with BK=16 makes the 16x16x4 fragment reads conflict-free
     constexpr int WGN = 4 / WGM;
     constexpr int WM = BM / WGM, WN = BN / WGN;
     constexpr int TM = WM / MF, TN = WN / MF;
@@ -58,7 +63,13 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(PatchK p) {
     const int ty = logical % p.tilesY; logical /= p.tilesY;
     const int b = logical % p.B;
     const int tn = logical / p.B;
-    const int oy0 = ty * TH, ox0 = tx * TW, n0 = tn * BN;
+    const int n0 = tn * BN;
+    // rectangle tiles: (oy0, ox0) origin, compile-time patch width; run tiles: pixel run [m0, m0+BM)
+    const int m0 = tx * BM;                                         // RUN only
+    const int oy0 = RUN ? m0 / p.Wo : ty * TH, ox0 = RUN ? 0 : tx * TW;
+    const int pw = RUN ? p.Wo + 2 : PW;                             // patch row length
+    const int ph = RUN ? (min(p.Ho * p.Wo, m0 + BM) - 1) / p.Wo - oy0 + 3 : PH;
+    const int npatch = ph * pw;
     const int Cin = p.Ca + p.Cb;
     const int HA = p.ups ? (p.Hi >> 1) : p.Hi, WA = p.ups ? (p.Wi >> 1) : p.Wi;
 
@@ -69,8 +80,8 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(PatchK p) {
         const int f = tid + it * 256;
         const int pp = f / F4;
         offA[it] = -1; offB[it] = -1;
-        if (f < P_SLOTS) {
-            const int pr = pp / PW, pc = pp - pr * PW;
+        if (f < P_SLOTS && pp < npatch) {
+            const int pr = pp / pw, pc = pp - pr * pw;
             int iy = oy0 - p.pad + pr, ix = ox0 - p.pad + pc;
             bool ok = true;
             if (p.pad_mode == CLSLAM_PAD_REFLECT) {
@@ -142,7 +153,12 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(PatchK p) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int m = wm0 + i * MF + frow;
-        prow[i] = (m / TW) * PW + (m % TW);
+        if constexpr (RUN) {
+            const int mm = min(m0 + m, p.Ho * p.Wo - 1);
+            prow[i] = (mm / p.Wo - oy0) * pw + (mm % p.Wo);
+        } else {
+            prow[i] = (m / TW) * PW + (m % TW);
+        }
     }
 
     load_global(0);
@@ -159,7 +175,7 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(PatchK p) {
                 float4 fa[TM], fb[TN];
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
-                    fa[i] = *reinterpret_cast<const float4*>(&Ps[(prow[i] + ky * PW + kx) * LD + kk * KSTEP + kg * 4]);
+                    fa[i] = *reinterpret_cast<const float4*>(&Ps[(prow[i] + ky * pw + kx) * LD + kk * KSTEP + kg * 4]);
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     fb[j] = *reinterpret_cast<const float4*>(&Wsm[((tap * BN) + wn0 + j * MF + frow) * LD + kk * KSTEP + kg * 4]);
@@ -195,8 +211,14 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(PatchK p) {
                 if constexpr (MF == 32) row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 else row = 4 * (lane >> 4) + r;
                 const int m = wm0 + i * MF + row;
-                const int oy = oy0 + m / TW, ox = ox0 + m % TW;
-                if (oy >= p.Ho || ox >= p.Wo) continue;
+                int oy, ox;
+                if constexpr (RUN) {
+                    if (m0 + m >= p.Ho * p.Wo) continue;
+                    oy = (m0 + m) / p.Wo; ox = (m0 + m) % p.Wo;
+                } else {
+                    oy = oy0 + m / TW; ox = ox0 + m % TW;
+                    if (oy >= p.Ho || ox >= p.Wo) continue;
+                }
                 const size_t o = (((size_t)b * p.Ho + oy) * p.Wo + ox) * p.Cout + n;
                 float v = acc[i][j][r] * sc + sh;
                 if (p.residual) v += p.residual[o];
@@ -208,13 +230,17 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(PatchK p) {
     }
 }
 
-template <int TH, int TW, int BN, int BK, int MF, int WGM>
+template <int TH, int TW, int BN, int BK, int MF, int WGM, bool RUN = false, int LDPAD = 4>
 static int launch_patch(PatchK k, hipStream_t stream) {
-    k.tilesX = cdiv(k.Wo, TW);
-    k.tilesY = cdiv(k.Ho, TH);
+    if (RUN) {
+        const int spanned = (TH * TW - 1 + k.Wo - 1) / k.Wo + 1;
+        if ((spanned + 2) * (k.Wo + 2) > run_pp(TH * TW)) { set_error("conv2d: image too wide for run tiles (Wo=%d)", k.Wo); return CLSLAM_ERR_INVALID; }
+    }
+    k.tilesX = RUN ? cdiv(k.Ho * k.Wo, TH * TW) : cdiv(k.Wo, TW);
+    k.tilesY = RUN ? 1 : cdiv(k.Ho, TH);
     k.tilesN = cdiv(k.Cout, BN);
     k.nblk = k.tilesX * k.tilesY * k.tilesN * k.B;
-    hipLaunchKernelGGL((conv3x3_patch_kernel<TH, TW, BN, BK, MF, WGM>), dim3(k.nblk), dim3(256), 0, stream, k);
+    hipLaunchKernelGGL((conv3x3_patch_kernel<TH, TW, BN, BK, MF, WGM, RUN, LDPAD>), dim3(k.nblk), dim3(256), 0, stream, k);
     return check_launch("conv3x3_patch");
 }
 
@@ -240,6 +266,11 @@ int conv3x3_patch_dispatch(const clslam_conv_desc* d, int cfg, hipStream_t strea
         case 15: return launch_patch<16, 16, 16, 16, 16, 4>(k, stream);  // 256 px x 16 ch
         case 16: return launch_patch<8, 16, 32, 16, 16, 4>(k, stream);   // 128 px x 32 ch on 16x16x4
         case 17: return launch_patch<4, 16, 16, 16, 16, 4>(k, stream);   //  64 px x 16 ch (small images)
+        case 18: return launch_patch<4, 16, 16, 16, 16, 4, true>(k, stream);   // 64-px runs x 16 ch (narrow images)
+        case 19: return launch_patch<8, 16, 16, 16, 16, 4, true>(k, stream);   // 128-px runs x 16 ch
+        case 20: return launch_patch<8, 16, 16, 16, 16, 4, false, 8>(k, stream);  // = 12 with conflict-free rows
+        case 21: return launch_patch<4, 16, 16, 16, 16, 4, false, 8>(k, stream);  // = 17 with conflict-free rows
+        case 22: return launch_patch<4, 16, 16, 16, 16, 4, true, 8>(k, stream);   // = 18 with conflict-free rows
         default: set_error("conv2d: unknown patch config %d", cfg); return CLSLAM_ERR_INVALID;
     }
 }

@@ -54,6 +54,14 @@ CASES = [
     (1, 18, 20, 16, 16, 16, 3, 1, 1, True, 2, False, 15),
     (2, 9, 18, 16, 0, 32, 3, 1, 0, False, 1, True, 16),
     (2, 6, 20, 32, 0, 48, 3, 1, 0, False, 1, False, 17),
+    (3, 6, 20, 32, 0, 48, 3, 1, 0, False, 1, True, 18),
+    (2, 12, 40, 16, 16, 32, 3, 1, 1, True, 2, False, 18),
+    (2, 2, 4, 32, 0, 16, 3, 1, 1, False, 2, False, 18),
+    (2, 12, 40, 32, 0, 32, 3, 1, 0, False, 1, False, 19),
+    (1, 5, 22, 16, 0, 16, 3, 1, 0, False, 0, False, 19),
+    (1, 10, 36, 32, 0, 32, 3, 1, 1, False, 2, False, 20),
+    (2, 6, 20, 32, 0, 48, 3, 1, 0, False, 1, False, 21),
+    (2, 6, 20, 32, 0, 48, 3, 1, 0, False, 1, False, 22),
 ]
 
 

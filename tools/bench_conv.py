@@ -54,7 +54,7 @@ for name, bm, Hi, Wi, Ca, Cb, Cout, k, stride, refl, ups in LAYERS:
     out = torch.empty(Bn, Ho, Wo, Cout, device=dev)
     flops = 2.0 * Bn * Ho * Wo * Cout * k * k * (Ca + Cb)
     line = f'{name:32s} M={Bn*Ho*Wo:7d} {flops/1e9:7.2f} GF |'
-    cfgs = [-1, 2, 3, 4, 11, 12, 14, 15, 16, 17]
+    cfgs = [-1, 12, 20, 17, 21, 18, 22]
     for cfg in cfgs:
         try:
             t = timeit(lambda: ops.conv2d(xa, w, out, src_b=xb, ksize=k, stride=stride, pad_mode=refl, upsample_a=bool(ups),
