@@ -111,7 +111,8 @@ def test_adapt_matches_reference_golden(backend, case, B, steps):
                 # torch's BLAS-evaluated projection by ~1e-5 px, so roughly one pixel per step lands on the
                 # other side of a kink and moves a layer's gradient by up to ~1 %.  The kernels themselves
                 # are held to 2e-4 / 2e-5 in test_loss_stage.py / test_conv_bwd.py.
-                assert abs(float(grad.double().norm()) - gn) <= 3e-2 * gn, (name, float(grad.double().norm()), gn)
+                assert abs(float(grad.double().norm()) - gn) <= 3e-2 * gn + 2e-6, (name, float(grad.double().norm()), gn)  # +abs: 1-element
+                # bias gradients are residues of heavily cancelling sums
                 sl = g[pre + 'gradslice/' + name]
                 scale = max(float(np.abs(sl).max()), gn / math.sqrt(n))
                 # an isolated near-tie flip in the 4-way min (see tests/test_loss_stage.py) perturbs
