@@ -452,12 +452,16 @@ class Engine:
         """weight (+ bias) gradient of one conv into the gradient arena; bias_blocks > 0 means
         t.colsum already holds that many per-block column sums of dz (fused into fold_act_grad)."""
         desc = ops.conv_desc(desc_src[0], out_shape, src_b=desc_src[1], ksize=3 if taps == 9 else 1, **geom)
-        splits = ops.wgrad_splits(desc, 1024)
+        use_patch = ops.wgrad_patch_supported(desc)
+        splits = ops.wgrad_patch_splits(desc, 512) if use_patch else ops.wgrad_splits(desc, 512)
         n = cout * taps * cin
         if t.partial is None or t.partial_elems < splits * n:
             t.partial_elems = max(splits * n, 64 * 1024 * 1024 // 4)
             t.partial = torch.empty(t.partial_elems, device=self.device)
-        ops.conv_wgrad(desc, dz, t.partial, splits)
+        if use_patch:
+            ops.conv_wgrad_patch(desc, dz, t.partial, splits)
+        else:
+            ops.conv_wgrad(desc, dz, t.partial, splits)
         ops.reduce_partials(t.partial, self._slot(self.g, name_prefix + '.weight', n), n, splits)
         if bias_blocks:
             ops.reduce_partials(t.colsum, self._slot(self.g, name_prefix + '.bias', cout), cout, bias_blocks)

@@ -107,6 +107,19 @@ def conv_wgrad(desc, dz, partial, splits):
     return partial
 
 
+def wgrad_patch_supported(desc) -> bool:
+    return bool(_lib.get_lib().cdll.clslam_wgrad_patch_supported(C.byref(desc)))
+
+
+def wgrad_patch_splits(desc, target_blocks=1024) -> int:
+    return _lib.get_lib().cdll.clslam_wgrad_patch_splits(C.byref(desc), target_blocks)
+
+
+def conv_wgrad_patch(desc, dz, partial, splits):
+    _lib.get_lib().call('clslam_conv_wgrad_patch', C.byref(desc), _p(dz), _p(partial), splits, _stream(dz))
+    return partial
+
+
 def reduce_partials(partial, out, n, splits, scale=1.0):
     _lib.get_lib().call('clslam_reduce_partials', _p(partial), _p(out), n, splits, scale, _stream(out))
     return out

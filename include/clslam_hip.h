@@ -95,6 +95,11 @@ int clslam_fold_act_grad(const float* dxp, const float* yout, float* dz, float* 
 /* Weight gradient as an MFMA GEMM reducing over pixels; desc = the forward conv's descriptor. */
 int clslam_wgrad_splits(const clslam_conv_desc* desc, int target_blocks);
 int clslam_conv_wgrad(const clslam_conv_desc* desc, const float* dz, float* partial, int splits, void* stream);
+/* Same contract as clslam_conv_wgrad for 3x3 stride-1 convs on images wider than 24 px, with the dZ
+ * tile and the input patch resident in LDS (wgrad_patch.hip); splits from clslam_wgrad_patch_splits. */
+int clslam_wgrad_patch_supported(const clslam_conv_desc* desc);
+int clslam_wgrad_patch_splits(const clslam_conv_desc* desc, int target_blocks);
+int clslam_conv_wgrad_patch(const clslam_conv_desc* desc, const float* dz, float* partial, int splits, void* stream);
 /* out[i] = scale * sum_s partial[s*n + i] in a fixed order (deterministic).                    */
 int clslam_reduce_partials(const float* partial, float* out, size_t n, int splits, float scale, void* stream);
 /* bias gradient: column sums of x[rows][ch], stage 1 (follow with clslam_reduce_partials).     */

@@ -15,6 +15,10 @@ CASES = [
     (2, 4, 6, 64, 64, 64, 3, True, True, 2),      # upconv_2_1-like, 64-tiles
     (2, 6, 10, 64, 0, 64, 3, False, False, 1),    # pose_0-like (zero pad, relu)
     (2, 6, 10, 64, 0, 64, 1, False, False, 1),    # squeeze-like 1x1
+    (2, 10, 36, 16, 0, 16, 3, True, True, 2),     # wgrad_patch 16x16, ragged tiles
+    (1, 16, 32, 32, 0, 16, 3, True, False, 2),    # wgrad_patch 16x32
+    (1, 8, 48, 32, 64, 32, 3, True, True, 2),     # wgrad_patch 32x32 with concat
+    (2, 9, 40, 64, 0, 64, 3, False, False, 1),    # wgrad_patch 32x32, zero pad
 ]
 
 
@@ -70,6 +74,14 @@ def test_conv_backward_matches_autograd(case, backend):
         dw = torch.empty(n, device=dev)
         ops.reduce_partials(partial, dw, n, splits)
         assert rel_err(dw.cpu().view_as(w), w.grad) < 2e-5, (target, splits)
+    if ops.wgrad_patch_supported(desc):
+        for target in (1, 16):
+            splits = ops.wgrad_patch_splits(desc, target)
+            partial = torch.full((splits * w.numel(),), float('nan'), device=dev)
+            ops.conv_wgrad_patch(desc, dz_d, partial, splits)
+            dw = torch.empty(w.numel(), device=dev)
+            ops.reduce_partials(partial, dw, w.numel(), splits)
+            assert rel_err(dw.cpu().view_as(w), w.grad) < 2e-5, ('patch', target, splits)
     # ---- bias grad ---------------------------------------------------------------------------
     rows = B * H * W
     nb = ops.colsum_blocks(rows)

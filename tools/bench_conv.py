@@ -54,7 +54,7 @@ for name, bm, Hi, Wi, Ca, Cb, Cout, k, stride, refl, ups in LAYERS:
     out = torch.empty(Bn, Ho, Wo, Cout, device=dev)
     flops = 2.0 * Bn * Ho * Wo * Cout * k * k * (Ca + Cb)
     line = f'{name:32s} M={Bn*Ho*Wo:7d} {flops/1e9:7.2f} GF |'
-    cfgs = [-1, 12, 20, 17, 21, 18, 22]
+    cfgs = [-1]
     for cfg in cfgs:
         try:
             t = timeit(lambda: ops.conv2d(xa, w, out, src_b=xb, ksize=k, stride=stride, pad_mode=refl, upsample_a=bool(ups),
@@ -75,4 +75,14 @@ for name, bm, Hi, Wi, Ca, Cb, Cout, k, stride, refl, ups in LAYERS:
             ops.reduce_partials(part, dw, w.numel(), splits)
         t = timeit(f)
         line += f' | wg{target}(s{splits}):{flops/t/1e12:6.1f}'
+    if ops.wgrad_patch_supported(desc):
+        for target in (512, 1024, 2048):
+            splits = ops.wgrad_patch_splits(desc, target)
+            part = torch.empty(splits * w.numel(), device=dev)
+
+            def f2():
+                ops.conv_wgrad_patch(desc, dz, part, splits)
+                ops.reduce_partials(part, dw, w.numel(), splits)
+            t = timeit(f2)
+            line += f' | wgP{target}(s{splits}):{flops/t/1e12:6.1f}'
     print(line, flush=True)
