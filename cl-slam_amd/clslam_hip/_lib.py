@@ -14,7 +14,7 @@ from typing import Optional
 LIB_PATH = Path(__file__).resolve().parents[1] / 'lib' / 'libclslam_hip.so'
 
 OK = 0
-ACT_NONE, ACT_RELU, ACT_ELU = 0, 1, 2
+ACT_NONE, ACT_RELU, ACT_ELU, ACT_HSWISH, ACT_HSIGMOID = 0, 1, 2, 3, 4
 PAD_ZERO, PAD_REFLECT = 0, 1
 
 fptr = C.c_void_p
@@ -76,6 +76,11 @@ _SIGNATURES = {
     'clslam_disp_mean': [fptr, fptr, i32, i32, C.c_void_p],
     'clslam_loss_finalize': [C.POINTER(LossDesc), C.c_void_p],
     'clslam_photo_grad': [fptr, fptr, fptr, fptr, fptr, fptr, i32, i32, i32, C.c_void_p],
+    'clslam_mbv3_stem': [fptr, fptr, fptr, fptr, fptr, i32, i32, i32, C.c_void_p],
+    'clslam_dwconv': [fptr, fptr, fptr, fptr, fptr, i32, i32, i32, i32, i32, i32, i32, C.c_void_p],
+    'clslam_global_avgpool': [fptr, fptr, i32, i32, i32, C.c_void_p],
+    'clslam_se_gate': [fptr, fptr, fptr, fptr, fptr, fptr, i32, i32, i32, C.c_void_p],
+    'clslam_channel_scale': [fptr, fptr, i32, i32, i32, C.c_void_p],
     'clslam_adam_step': [fptr, fptr, fptr, fptr, C.c_size_t, C.c_double, C.c_double, C.c_double, C.c_double, i32, C.c_float,
                          C.c_void_p],
     'clslam_disp_grad': [fptr, fptr, fptr, i32, fptr, i32, i32, i32, i32, i32, C.c_void_p],

@@ -5,7 +5,7 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import ACT_ELU, ACT_NONE, ACT_RELU, PAD_REFLECT, PAD_ZERO  # noqa: F401
+from ._lib import ACT_ELU, ACT_HSIGMOID, ACT_HSWISH, ACT_NONE, ACT_RELU, PAD_REFLECT, PAD_ZERO  # noqa: F401
 
 
 # bench.py sets this to a list to collect (kernel, tile config, algorithmic flops, start, end) per conv launch
@@ -266,3 +266,36 @@ def disp_grad(ddisp_up, disp, smooth_aux, n_smooth, dz, H, W):
 def adam_step(param, grad, exp_avg, exp_avg_sq, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
     _lib.get_lib().call('clslam_adam_step', _p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(), lr, beta1,
                         beta2, eps, step, grad_scale, _stream(param))
+
+
+# ---- loop-closure encoder (MobileNetV3-small) ops ------------------------------------------------
+def mbv3_stem(img, weight, scale, shift, out):
+    B, _, H, W = img.shape
+    _lib.get_lib().call('clslam_mbv3_stem', _p(img), _p(weight), _p(scale), _p(shift), _p(out), B, H, W, _stream(out))
+    return out
+
+
+def dwconv(x, weight, scale, shift, out, ksize, stride, act):
+    B, H, W, Cc = x.shape
+    _lib.get_lib().call('clslam_dwconv', _p(x), _p(weight), _p(scale), _p(shift), _p(out), B, H, W, Cc, ksize, stride, act,
+                        _stream(out))
+    return out
+
+
+def global_avgpool(x, out):
+    B, Cc = x.shape[0], x.shape[-1]
+    _lib.get_lib().call('clslam_global_avgpool', _p(x), _p(out), B, x.numel() // (B * Cc), Cc, _stream(out))
+    return out
+
+
+def se_gate(pool, w1, b1, w2, b2, gate):
+    B, Cc = pool.shape
+    _lib.get_lib().call('clslam_se_gate', _p(pool), _p(w1), _p(b1), _p(w2), _p(b2), _p(gate), B, Cc, w1.shape[0],
+                        _stream(gate))
+    return gate
+
+
+def channel_scale(x, gate):
+    B, Cc = x.shape[0], x.shape[-1]
+    _lib.get_lib().call('clslam_channel_scale', _p(x), _p(gate), B, x.numel() // (B * Cc), Cc, _stream(x))
+    return x

@@ -30,6 +30,8 @@ __device__ __forceinline__ int reflect_idx(int i, int n) {  // ReflectionPad2d s
 __device__ __forceinline__ float apply_act(float v, int act) {
     if (act == CLSLAM_ACT_RELU) return v > 0.f ? v : 0.f;
     if (act == CLSLAM_ACT_ELU) return v > 0.f ? v : expm1f(v);
+    if (act == CLSLAM_ACT_HSWISH) return v * fminf(fmaxf(v + 3.f, 0.f), 6.f) / 6.f;
+    if (act == CLSLAM_ACT_HSIGMOID) return fminf(fmaxf(v + 3.f, 0.f), 6.f) / 6.f;
     return v;
 }
 

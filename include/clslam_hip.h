@@ -31,6 +31,8 @@ extern "C" {
 #define CLSLAM_ACT_NONE 0
 #define CLSLAM_ACT_RELU 1
 #define CLSLAM_ACT_ELU 2
+#define CLSLAM_ACT_HSWISH 3   /* x * relu6(x+3) / 6   (MobileNetV3) */
+#define CLSLAM_ACT_HSIGMOID 4 /* relu6(x+3) / 6 */
 
 #define CLSLAM_PAD_ZERO 0
 #define CLSLAM_PAD_REFLECT 1
@@ -207,6 +209,25 @@ int clslam_disp_grad(const float* ddisp_up, const float* disp, const float* smoo
  * grad_scale first (1 for single GPU; data-parallel ranks all-reduce with SUM, so it stays 1).  */
 int clslam_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, double lr,
                      double beta1, double beta2, double eps, int step, float grad_scale, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Loop-closure feature encoder: MobileNetV3-small forward (loop_closure_detection/encoder.py:13-33:
+ * torchvision mobilenet_v3_small cut at 'flatten', ImageNet mean/std normalisation).  The 1x1 convs
+ * run through clslam_conv2d (channels zero-padded to multiples of 16); these are the other ops.
+ * PARITY UNPINNED: torchvision's source/weights are not available to the build. */
+/* normalise + conv3x3 s2 p1 (3->16) + BN + hardswish; img planar (B,3,h,w), weight OIHW (16,3,3,3) */
+int clslam_mbv3_stem(const float* img, const float* weight, const float* scale, const float* shift, float* out,
+                     int batch, int h, int w, void* stream);
+/* depthwise k x k (3|5), stride 1|2, pad k/2, NHWC, weight [k*k][ch], BN scale/shift, activation   */
+int clslam_dwconv(const float* x, const float* weight, const float* scale, const float* shift, float* out, int batch,
+                  int h, int w, int ch, int ksize, int stride, int act, void* stream);
+/* out[b][c] = mean over pixels of x[b][p][c]                                                      */
+int clslam_global_avgpool(const float* x, float* out, int batch, int hw, int ch, void* stream);
+/* squeeze-excitation gates: gate[b][c] = hardsigmoid(w2 * relu(w1 * pool[b] + b1) + b2)            */
+int clslam_se_gate(const float* pool, const float* w1, const float* b1, const float* w2, const float* b2, float* gate,
+                   int batch, int ch, int squeeze, void* stream);
+/* x[b][p][c] *= gate[b][c] (in place)                                                             */
+int clslam_channel_scale(float* x, const float* gate, int batch, int hw, int ch, void* stream);
 
 #ifdef __cplusplus
 }
