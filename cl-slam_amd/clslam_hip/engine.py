@@ -17,6 +17,7 @@ Reference call graph being replaced: dpp.py:906-923 (_process_batch), :925-974, 
 :1019-1120, and dpp.py:309-313 (zero_grad / backward / optimizer.step).
 """
 import math
+import os
 from types import SimpleNamespace
 from typing import Any, Dict, List, Optional, Tuple
 
@@ -119,6 +120,11 @@ class Engine:
         self._packed_version = None
         self._modules_stale = False
         self.fresh_outputs = True
+        # the depth net and the pose net are independent until the loss stage (and their backward passes
+        # after it): run the pose branch on a second HIP stream so its small 6x20 layers fill the CUs the
+        # depth branch leaves idle at kernel tails
+        self.side_stream = torch.cuda.Stream(device=device) if device.type == 'cuda' else None
+        self.use_side_stream = os.environ.get('CLSLAM_SIDE_STREAM', '1') != '0'
 
     # ------------------------------------------------------------------------------------------
     # parameters
@@ -286,6 +292,7 @@ class Engine:
         t.partial_elems = 0
         t.colsum = E(1024 * 256)
         t.disp_part = E(512 * (9 * 128 + 1))
+        t.side = SimpleNamespace(partial=None, partial_elems=0, colsum=E(1024 * 256), wt=E(256 * 9 * 256))
         ws.train = t
         return t
 
@@ -363,11 +370,23 @@ class Engine:
             ws.pose, ws.T = E(2 * B, 12), E(2, B, 4, 4)
             ws.depth, ws.warped, ws.losses = E(4, B, H, W), E(4, 2, B, 3, H, W), E(18)
         # networks ---------------------------------------------------------------------------
-        dfeats = self._encoder(self.enc['depth_encoder'], ws.denc, B, [(aug[0], None, 0, B)])
-        self._depth_decoder(ws, dfeats)
-        # pose pairs in temporal order (dpp.py:949-955): (-1, 0) and (0, +1), batched as 2B
-        pfeats = self._encoder(self.enc['pose_encoder'], ws.penc, 2 * B, [(aug[-1], aug[0], 0, B), (aug[0], aug[1], B, B)])
-        self._pose_decoder(ws, pfeats[4])
+        side = self.side_stream if (self.use_side_stream and self.side_stream is not None) else None
+        if side is not None:
+            main = torch.cuda.current_stream(self.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                # pose pairs in temporal order (dpp.py:949-955): (-1, 0) and (0, +1), batched as 2B
+                pfeats = self._encoder(self.enc['pose_encoder'], ws.penc, 2 * B,
+                                       [(aug[-1], aug[0], 0, B), (aug[0], aug[1], B, B)])
+                self._pose_decoder(ws, pfeats[4])
+            dfeats = self._encoder(self.enc['depth_encoder'], ws.denc, B, [(aug[0], None, 0, B)])
+            self._depth_decoder(ws, dfeats)
+            main.wait_stream(side)
+        else:
+            dfeats = self._encoder(self.enc['depth_encoder'], ws.denc, B, [(aug[0], None, 0, B)])
+            self._depth_decoder(ws, dfeats)
+            pfeats = self._encoder(self.enc['pose_encoder'], ws.penc, 2 * B, [(aug[-1], aug[0], 0, B), (aug[0], aug[1], B, B)])
+            self._pose_decoder(ws, pfeats[4])
         ws.dfeats, ws.pf4 = dfeats, pfeats[4]
         # view synthesis + loss ------------------------------------------------------------------
         K = self._mat(inputs['camera_matrix', 0])
@@ -485,6 +504,21 @@ class Engine:
                          self.max_depth)
             ops.disp_grad(t.ddisp_up, ws.disp[s], c.aux[s] if c.n_smooth else None, c.n_smooth, t.dz_disp[s], H, W)
         ops.pose_bwd(t.dp_partial, 4, t.nb2, ws.pose, c.K, c.d0, c.d1, c.sample_w, self.vel_scale, t.dpose)
+        side = self.side_stream if (self.use_side_stream and self.side_stream is not None) else None
+        if side is not None:
+            main = torch.cuda.current_stream(self.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                self._backward_pose_decoder(ws, t, B, t.side)
+            self._backward_depth_decoder(ws, t, B)
+            main.wait_stream(side)
+        else:
+            self._backward_depth_decoder(ws, t, B)
+            self._backward_pose_decoder(ws, t, B, t)
+
+    def _backward_depth_decoder(self, ws, t, B: int) -> None:
+        H, W = self.H, self.W
+        feats = ws.dfeats
         # depth decoder -----------------------------------------------------------------------------
         dxp_in = None  # padded-domain gradient w.r.t. x[i,1] coming from upconv_{i-1}_0
         for i in range(5):
@@ -529,23 +563,27 @@ class Engine:
                 ops.weight_transpose(w0, wt)
                 dxp_in = t.dxp[0][:B * (h2 + 2) * (w2 + 2) * cin0].view(B, h2 + 2, w2 + 2, cin0)
                 ops.conv2d(t.dz[i, 0], wt, dxp_in, ksize=3, pad=2)
-        # pose decoder --------------------------------------------------------------------------------
+
+    def _backward_pose_decoder(self, ws, t, B: int, scratch) -> None:
+        """`scratch` supplies the partial / colsum / wt buffers (a separate set when the pose branch runs
+        concurrently with the depth branch)."""
+        H, W = self.H, self.W
         n2 = 2 * B
         h5, w5 = H >> 5, W >> 5
         w2_, _ = self._wb('pose_decoder/pose_2', 12, 256, 1)
         ops.pose_head_bwd(t.dpose, ws.p1, w2_.view(12, 256), ws.pmean, t.dz_p1,
                           self._slot(self.g, 'pose_decoder/pose_2.weight', 12 * 256).view(12, 256),
                           self._slot(self.g, 'pose_decoder/pose_2.bias', 12))
-        self._wgrad(t, (ws.p0, None), (n2, h5, w5, 256), t.dz_p1, 'pose_decoder/pose_1', 256, 256, 9)
+        self._wgrad(scratch, (ws.p0, None), (n2, h5, w5, 256), t.dz_p1, 'pose_decoder/pose_1', 256, 256, 9)
         wp1, _ = self._wb('pose_decoder/pose_1', 256, 256, 9)
-        wt = t.wt[:256 * 9 * 256].view(256, 9, 256)
+        wt = scratch.wt[:256 * 9 * 256].view(256, 9, 256)
         ops.weight_transpose(wp1, wt)
         ops.conv2d(t.dz_p1, wt, t.dz_p0, ksize=3, pad=1, actgrad_src=ws.p0, actgrad_kind=ACT_RELU)
-        self._wgrad(t, (ws.sq, None), (n2, h5, w5, 256), t.dz_p0, 'pose_decoder/pose_0', 256, 256, 9)
+        self._wgrad(scratch, (ws.sq, None), (n2, h5, w5, 256), t.dz_p0, 'pose_decoder/pose_0', 256, 256, 9)
         wp0, _ = self._wb('pose_decoder/pose_0', 256, 256, 9)
         ops.weight_transpose(wp0, wt)
         ops.conv2d(t.dz_p0, wt, t.dz_sq, ksize=3, pad=1, actgrad_src=ws.sq, actgrad_kind=ACT_RELU)
-        self._wgrad(t, (ws.pf4, None), (n2, h5, w5, 256), t.dz_sq, 'pose_decoder/squeeze', 256, 512, 1, pad=0)
+        self._wgrad(scratch, (ws.pf4, None), (n2, h5, w5, 256), t.dz_sq, 'pose_decoder/squeeze', 256, 512, 1, pad=0)
 
     # ------------------------------------------------------------------------------------------
     def adam(self, lr: float, betas=(0.9, 0.999), eps: float = 1e-8) -> None:
