@@ -124,6 +124,7 @@ class Engine:
         # after it): run the pose branch on a second HIP stream so its small 6x20 layers fill the CUs the
         # depth branch leaves idle at kernel tails
         self.side_stream = torch.cuda.Stream(device=device) if device.type == 'cuda' else None
+        self.wg_stream = torch.cuda.Stream(device=device) if device.type == 'cuda' else None
         self.use_side_stream = os.environ.get('CLSLAM_SIDE_STREAM', '1') != '0'
 
     # ------------------------------------------------------------------------------------------
@@ -293,6 +294,8 @@ class Engine:
         t.colsum = E(1024 * 256)
         t.disp_part = E(512 * (9 * 128 + 1))
         t.side = SimpleNamespace(partial=None, partial_elems=0, colsum=E(1024 * 256), wt=E(256 * 9 * 256))
+        t.wg = SimpleNamespace(partial=None, partial_elems=0, colsum=E(1024 * 256), disp_part=E(512 * (9 * 128 + 1)))
+        t.bias_part = {k: E(1024 * v.shape[-1]) for k, v in ws.x.items()}   # fused bias-grad partials per layer
         ws.train = t
         return t
 
@@ -467,9 +470,9 @@ class Engine:
     # ------------------------------------------------------------------------------------------
     # backward
     def _wgrad(self, t, desc_src, out_shape, dz, name_prefix: str, cout: int, cin: int, taps: int, bias_blocks: int = 0,
-               **geom) -> None:
+               bias_partial=None, **geom) -> None:
         """weight (+ bias) gradient of one conv into the gradient arena; bias_blocks > 0 means
-        t.colsum already holds that many per-block column sums of dz (fused into fold_act_grad)."""
+        bias_partial already holds that many per-block column sums of dz (fused into fold_act_grad)."""
         desc = ops.conv_desc(desc_src[0], out_shape, src_b=desc_src[1], ksize=3 if taps == 9 else 1, **geom)
         use_patch = ops.wgrad_patch_supported(desc)
         splits = ops.wgrad_patch_splits(desc, 512) if use_patch else ops.wgrad_splits(desc, 512)
@@ -483,7 +486,7 @@ class Engine:
             ops.conv_wgrad(desc, dz, t.partial, splits)
         ops.reduce_partials(t.partial, self._slot(self.g, name_prefix + '.weight', n), n, splits)
         if bias_blocks:
-            ops.reduce_partials(t.colsum, self._slot(self.g, name_prefix + '.bias', cout), cout, bias_blocks)
+            ops.reduce_partials(bias_partial, self._slot(self.g, name_prefix + '.bias', cout), cout, bias_blocks)
             return
         rows = out_shape[0] * out_shape[1] * out_shape[2]
         nb = ops.colsum_blocks(rows)
@@ -517,9 +520,26 @@ class Engine:
             self._backward_pose_decoder(ws, t, B, t)
 
     def _backward_depth_decoder(self, ws, t, B: int) -> None:
+        """dgrad chain (critical path) on the current stream; every weight/bias gradient is independent
+        of the rest of the chain once its dz exists, so those run on a third stream (`wg_stream`)."""
         H, W = self.H, self.W
         feats = ws.dfeats
-        # depth decoder -----------------------------------------------------------------------------
+        main = torch.cuda.current_stream(self.device) if self.device.type == 'cuda' else None
+        wg = self.wg_stream if (self.use_side_stream and self.wg_stream is not None) else None
+        if wg is not None:
+            wg.wait_stream(main)
+
+        def on_wg(fn):
+            """run fn on the wgrad stream after everything enqueued so far on the main stream"""
+            if wg is None:
+                fn()
+                return
+            ev = torch.cuda.Event()
+            ev.record(main)
+            wg.wait_event(ev)
+            with torch.cuda.stream(wg):
+                fn()
+
         dxp_in = None  # padded-domain gradient w.r.t. x[i,1] coming from upconv_{i-1}_0
         for i in range(5):
             hi, wi, ci = H >> i, W >> i, NUM_CH_DEC[i]
@@ -530,19 +550,22 @@ class Engine:
                     ops.dispconv_bwd_data(t.dz_disp[i], wd.view(9, ci), dxp_in, ci, accumulate=False)
                 else:
                     ops.dispconv_bwd_data(t.dz_disp[i], wd.view(9, ci), dxp_in, ci, accumulate=True)
-                # dispconv weight + bias gradient
-                nb = ops.dispconv_wgrad_blocks(B * hi * wi)
-                ops.dispconv_wgrad(t.dz_disp[i], ws.x[i, 1], t.disp_part)
-                ops.reduce_partials(t.disp_part, self._slot(self.g, f'depth_decoder/dispconv_{i}.conv.weight', 9 * ci + 1),
-                                    9 * ci + 1, nb)
+
+                def disp_wgrad(i=i, hi=hi, wi=wi, ci=ci):   # dispconv weight + bias gradient
+                    nb = ops.dispconv_wgrad_blocks(B * hi * wi)
+                    ops.dispconv_wgrad(t.dz_disp[i], ws.x[i, 1], t.wg.disp_part)
+                    ops.reduce_partials(t.wg.disp_part, self._slot(self.g, f'depth_decoder/dispconv_{i}.conv.weight', 9 * ci + 1),
+                                        9 * ci + 1, nb)
+                on_wg(disp_wgrad)
             nb1 = ops.fold_blocks(B, hi, wi, ci, False)
             ops.fold_act_grad(dxp_in, ws.x[i, 1], t.dz[i, 1], h=hi, w=wi, ch=ci, border=1, pool=False, act=ACT_ELU,
-                              bias_partial=t.colsum)
+                              bias_partial=t.bias_part[i, 1])
             # upconv_i_1: input = cat(up(x[i,0]), feats[i-1])
             skip = feats[i - 1] if i > 0 else None
             cin1 = ci + (NUM_CH_ENC[i - 1] if i > 0 else 0)
-            self._wgrad(t, (ws.x[i, 0], skip), (B, hi, wi, ci), t.dz[i, 1], f'depth_decoder/upconv_{i}_1.conv.conv', ci, cin1, 9,
-                        bias_blocks=nb1, pad_mode=PAD_REFLECT, upsample_a=True)
+            on_wg(lambda i=i, hi=hi, wi=wi, ci=ci, skip=skip, cin1=cin1, nb1=nb1: self._wgrad(
+                t.wg, (ws.x[i, 0], skip), (B, hi, wi, ci), t.dz[i, 1], f'depth_decoder/upconv_{i}_1.conv.conv', ci, cin1, 9,
+                bias_blocks=nb1, bias_partial=t.bias_part[i, 1], pad_mode=PAD_REFLECT, upsample_a=True))
             w1, _ = self._wb(f'depth_decoder/upconv_{i}_1.conv.conv', ci, cin1, 9)
             wt = t.wt[:ci * 9 * ci].view(ci, 9, ci)
             ops.weight_transpose(w1, wt, ch_in_sel=ci)          # only the up(x[i,0]) half: the skip half is frozen
@@ -550,19 +573,22 @@ class Engine:
             ops.conv2d(t.dz[i, 1], wt, dxa, ksize=3, pad=2)
             nb0 = ops.fold_blocks(B, hi, wi, ci, True)
             ops.fold_act_grad(dxa, ws.x[i, 0], t.dz[i, 0], h=hi, w=wi, ch=ci, border=1, pool=True, act=ACT_ELU,
-                              bias_partial=t.colsum)
+                              bias_partial=t.bias_part[i, 0])
             # upconv_i_0: input = x[i+1,1] (or the frozen encoder feature for i == 4)
             src = ws.x[i + 1, 1] if i < 4 else feats[4]
             cin0 = NUM_CH_ENC[-1] if i == 4 else NUM_CH_DEC[i + 1]
             h2, w2 = hi >> 1, wi >> 1
-            self._wgrad(t, (src, None), (B, h2, w2, ci), t.dz[i, 0], f'depth_decoder/upconv_{i}_0.conv.conv', ci, cin0, 9,
-                        bias_blocks=nb0, pad_mode=PAD_REFLECT)
+            on_wg(lambda i=i, h2=h2, w2=w2, ci=ci, src=src, cin0=cin0, nb0=nb0: self._wgrad(
+                t.wg, (src, None), (B, h2, w2, ci), t.dz[i, 0], f'depth_decoder/upconv_{i}_0.conv.conv', ci, cin0, 9,
+                bias_blocks=nb0, bias_partial=t.bias_part[i, 0], pad_mode=PAD_REFLECT))
             if i < 4:
                 w0, _ = self._wb(f'depth_decoder/upconv_{i}_0.conv.conv', ci, cin0, 9)
                 wt = t.wt[:cin0 * 9 * ci].view(cin0, 9, ci)
                 ops.weight_transpose(w0, wt)
                 dxp_in = t.dxp[0][:B * (h2 + 2) * (w2 + 2) * cin0].view(B, h2 + 2, w2 + 2, cin0)
                 ops.conv2d(t.dz[i, 0], wt, dxp_in, ksize=3, pad=2)
+        if wg is not None:
+            main.wait_stream(wg)
 
     def _backward_pose_decoder(self, ws, t, B: int, scratch) -> None:
         """`scratch` supplies the partial / colsum / wt buffers (a separate set when the pose branch runs
