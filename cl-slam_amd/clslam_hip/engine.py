@@ -116,6 +116,7 @@ class Engine:
         self.adam_step_count = 0
         self.enc: Dict[str, Any] = {}
         self._ws: Dict[int, SimpleNamespace] = {}
+        self._graphs: Dict[Any, SimpleNamespace] = {}
         self.models = None
         self._packed_version = None
         self._modules_stale = False
@@ -356,7 +357,7 @@ class Engine:
     # ------------------------------------------------------------------------------------------
     def forward(self, inputs: Dict[Any, torch.Tensor], *, train: bool, sample_w: torch.Tensor,
                 smooth_w: Optional[torch.Tensor], noise: Optional[Dict[int, torch.Tensor]] = None,
-                draw_noise: bool = True) -> Tuple[Dict[Any, torch.Tensor], torch.Tensor]:
+                draw_noise: bool = True, keep_noise: bool = False) -> Tuple[Dict[Any, torch.Tensor], torch.Tensor]:
         """One _process_batch (dpp.py:906-923).  `inputs` tensors must already live on the device."""
         H, W = self.H, self.W
         aug = {f: self._img(inputs['rgb_aug', f, 0]) for f in (-1, 0, 1)}
@@ -403,6 +404,8 @@ class Engine:
         if noise is not None:
             for s in range(4):
                 ws.noise[s].copy_(noise[s])
+            have_noise = True
+        elif keep_noise:                       # already copied into ws.noise by the graph driver
             have_noise = True
         elif draw_noise:
             ws.noise.normal_().mul_(1e-5)  # dpp.py:1055-1056
@@ -610,6 +613,67 @@ class Engine:
         ops.weight_transpose(wp0, wt)
         ops.conv2d(t.dz_p0, wt, t.dz_sq, ksize=3, pad=1, actgrad_src=ws.sq, actgrad_kind=ACT_RELU)
         self._wgrad(scratch, (ws.pf4, None), (n2, h5, w5, 256), t.dz_sq, 'pose_decoder/squeeze', 256, 512, 1, pad=0)
+
+    # ------------------------------------------------------------------------------------------
+    # hipGraph: the whole forward+backward of a training step is ~230 kernel launches over three
+    # streams; replaying it as one graph removes the Python/ctypes launch cost (the step is otherwise
+    # host-bound once the kernels take < 5 ms) and keeps the cross-stream concurrency.
+    GRAPH_KEYS = ([('rgb_aug', f, 0) for f in (-1, 0, 1)] + [('rgb', f, 0) for f in (-1, 0, 1)] +
+                  [('rgb', 0, s) for s in (1, 2, 3)] + [('camera_matrix', 0), ('inv_camera_matrix', 0),
+                                                        ('relative_distance', 0), ('relative_distance', 1)])
+
+    def graphs_enabled(self) -> bool:
+        return (self.device.type == 'cuda' and os.environ.get('CLSLAM_HIPGRAPH', '1') != '0' and ops.PROFILE is None)
+
+    def train_step_graphed(self, inputs: Dict[Any, torch.Tensor], *, sample_w: torch.Tensor, smooth_w: Optional[torch.Tensor],
+                           noise: Optional[Dict[int, torch.Tensor]], copy_inputs: bool = True):
+        """forward(train=True) + backward() through a captured hipGraph (captured on first use per
+        batch size / noise mode).  Returns (outputs, losses) as fresh tensors."""
+        B = inputs['rgb_aug', 0, 0].shape[0]
+        key = (B, noise is not None, 0 if smooth_w is None else int(smooth_w.numel()))
+        st = self._graphs.get(key)
+        if st is None:
+            st = SimpleNamespace(graph=None, inputs={}, sample_w=sample_w.clone(),
+                                 smooth_w=None if smooth_w is None else smooth_w.clone(), outputs=None, losses=None)
+            for k in self.GRAPH_KEYS:
+                v = inputs[k]
+                st.inputs[k] = (v.to(torch.float64) if k[0] == 'relative_distance' else self._img(v)).clone()
+            self._graphs[key] = st
+        elif copy_inputs:
+            for k in self.GRAPH_KEYS:
+                st.inputs[k].copy_(inputs[k], non_blocking=True)
+        st.sample_w.copy_(sample_w, non_blocking=True)
+        if smooth_w is not None:
+            st.smooth_w.copy_(smooth_w, non_blocking=True)
+        ws = self.workspace(B)
+        if noise is not None:
+            for s in range(4):
+                ws.noise[s].copy_(noise[s], non_blocking=True)
+        if st.graph is None:
+            def run():
+                out, losses = self.forward(st.inputs, train=True, sample_w=st.sample_w, smooth_w=st.smooth_w,
+                                           noise=None, draw_noise=noise is None, keep_noise=noise is not None)
+                self.backward(B)
+                return out, losses
+            fresh = self.fresh_outputs
+            self.fresh_outputs = False          # the graph writes into static planes; copies are handed out
+            try:
+                cur = torch.cuda.current_stream(self.device)
+                warm = torch.cuda.Stream(device=self.device)
+                warm.wait_stream(cur)
+                with torch.cuda.stream(warm):   # eager warm-up: allocates every workspace buffer
+                    run()
+                cur.wait_stream(warm)
+                torch.cuda.synchronize(self.device)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    st.outputs, st.losses = run()
+                st.graph = g
+            finally:
+                self.fresh_outputs = fresh
+        st.graph.replay()
+        outputs = {k: v.clone() for k, v in st.outputs.items()}
+        return outputs, st.losses.clone()
 
     # ------------------------------------------------------------------------------------------
     def adam(self, lr: float, betas=(0.9, 0.999), eps: float = 1e-8) -> None:

@@ -261,10 +261,17 @@ class DepthPosePrediction:
         if training_data is not None:
             self._set_adapt(freeze_encoder=True)
             self.engine.pack_if_needed()
-            for _ in range(steps):
-                outputs_eval, losses = self._process_batch(training_data, loss_weights, train=True)
-                self.optimizer.zero_grad()
-                self._backward(training_data)
+            for it in range(steps):
+                if self.engine.graphs_enabled():
+                    # forward + backward replayed as one hipGraph (same kernels, same streams)
+                    outputs_eval, losses = self._process_batch(training_data, loss_weights, train=True, graphed=True,
+                                                               copy_inputs=(it == 0))
+                    self.optimizer.zero_grad()
+                    self._reduce_gradients()
+                else:
+                    outputs_eval, losses = self._process_batch(training_data, loss_weights, train=True)
+                    self.optimizer.zero_grad()
+                    self._backward(training_data)
                 self.optimizer.step()
         else:
             self._set_eval()
@@ -416,13 +423,17 @@ class DepthPosePrediction:
         return w, w
 
     def _process_batch(self, inputs: Dict[Any, Tensor], loss_sample_weights: Optional[Tensor] = None,
-                       use_online: bool = False, train: bool = False):
+                       use_online: bool = False, train: bool = False, graphed: bool = False, copy_inputs: bool = True):
         for key, val in inputs.items():  # mutates the caller's dict, like dpp.py:916-917
             inputs[key] = val.to(self.device)
         B = inputs['rgb_aug', 0, 0].shape[0]
         sample_w, smooth_w = self._sample_weights(B, loss_sample_weights)
-        outputs, losses = self.engine.forward(inputs, train=train, sample_w=sample_w, smooth_w=smooth_w,
-                                              noise=self._injected_noise)
+        if graphed:
+            outputs, losses = self.engine.train_step_graphed(inputs, sample_w=sample_w, smooth_w=smooth_w,
+                                                             noise=self._injected_noise, copy_inputs=copy_inputs)
+        else:
+            outputs, losses = self.engine.forward(inputs, train=train, sample_w=sample_w, smooth_w=smooth_w,
+                                                  noise=self._injected_noise)
         if self._dp is not None:
             self._dp['dist'].all_reduce(losses, group=self._dp['group'])
         loss_dict = self.engine.losses_dict(losses)
@@ -435,6 +446,9 @@ class DepthPosePrediction:
     def _backward(self, inputs: Dict[Any, Tensor]) -> None:
         B = inputs['rgb_aug', 0, 0].shape[0]
         self.engine.backward(B)
+        self._reduce_gradients()
+
+    def _reduce_gradients(self) -> None:
         if self._dp is not None:
             self._dp['dist'].all_reduce(self.engine.g, group=self._dp['group'])
 
