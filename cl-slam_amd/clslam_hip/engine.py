@@ -119,6 +119,7 @@ class Engine:
         self._graphs: Dict[Any, SimpleNamespace] = {}
         self.models = None
         self._packed_version = None
+        self._tracked = None
         self._modules_stale = False
         self.fresh_outputs = True
         # the depth net and the pose net are independent until the loss stage (and their backward passes
@@ -136,11 +137,11 @@ class Engine:
             m._bind(self, name)
 
     def _module_version(self) -> int:
-        v = 0
-        for m in self.models.values():
-            for t in torch.nn.Module.state_dict(m, keep_vars=True).values():
-                v += t._version
-        return v
+        """cheap fingerprint of the module parameters/buffers (in-place edits bump ``_version``;
+        load_state_dict copies in place, so the tensor objects themselves are stable)"""
+        if self._tracked is None:
+            self._tracked = [t for m in self.models.values() for t in torch.nn.Module.state_dict(m, keep_vars=True).values()]
+        return sum(t._version for t in self._tracked)
 
     def pack_if_needed(self) -> None:
         """Re-layout the module parameters into the engine's buffers when they were modified from
@@ -623,7 +624,14 @@ class Engine:
                                                         ('relative_distance', 0), ('relative_distance', 1)])
 
     def graphs_enabled(self) -> bool:
-        return (self.device.type == 'cuda' and os.environ.get('CLSLAM_HIPGRAPH', '1') != '0' and ops.PROFILE is None)
+        return (self.device.type == 'cuda' and os.environ.get('CLSLAM_HIPGRAPH', 'auto') != '0' and ops.PROFILE is None)
+
+    def graph_preferred(self, B: int) -> bool:
+        """Measured on MI355X (tools/time_step.py): with B >= 3 the step is GPU-bound and graph replay of the
+        three-stream schedule is no faster than eager launches (4.63 vs 4.51 ms at B=5); small batches are
+        host-bound (~2.2 ms of Python/ctypes launch time per step) and gain.  CLSLAM_HIPGRAPH=1 forces it."""
+        mode = os.environ.get('CLSLAM_HIPGRAPH', 'auto')
+        return self.graphs_enabled() and (mode == '1' or B <= 2)
 
     def train_step_graphed(self, inputs: Dict[Any, torch.Tensor], *, sample_w: torch.Tensor, smooth_w: Optional[torch.Tensor],
                            noise: Optional[Dict[int, torch.Tensor]], copy_inputs: bool = True):

@@ -215,6 +215,7 @@ class DepthPosePrediction:
 
         self._dp = None
         self._injected_noise = None
+        self._mode = None
 
     # ============================================================
     # Data-parallel replay minibatch (new functionality; the reference has no multi-GPU adaptation)
@@ -262,7 +263,7 @@ class DepthPosePrediction:
             self._set_adapt(freeze_encoder=True)
             self.engine.pack_if_needed()
             for it in range(steps):
-                if self.engine.graphs_enabled():
+                if self.engine.graph_preferred(training_data['rgb_aug', 0, 0].shape[0]):
                     # forward + backward replayed as one hipGraph (same kernels, same streams)
                     outputs_eval, losses = self._process_batch(training_data, loss_weights, train=True, graphed=True,
                                                                copy_inputs=(it == 0))
@@ -386,14 +387,20 @@ class DepthPosePrediction:
     def _set_train(self) -> None:
         for m in self.models.values():
             m.train()
+        self._mode = 'train'
 
     def _set_eval(self) -> None:
+        if self._mode in ('eval', 'adapt'):   # both are eval() for the modules; walking them costs ~0.1 ms
+            return
         for m in self.models.values():
             m.eval()
+        self._mode = 'eval'
 
     def _set_adapt(self, freeze_encoder: bool = True) -> None:
         if not freeze_encoder:
             raise ValueError('the accelerated path implements freeze_encoder=True (dpp.py:308)')
+        if self._mode == 'adapt':             # idempotent (requires_grad is never re-enabled)
+            return
         for model_name, model in self.models.items():
             model.eval()
             for name, param in torch.nn.Module.named_parameters(model):
@@ -401,6 +408,7 @@ class DepthPosePrediction:
                     param.requires_grad = False
                 if 'encoder' in model_name:
                     param.requires_grad = False
+        self._mode = 'adapt'
 
     # ============================================================
     def _sample_weights(self, B: int, loss_sample_weights: Optional[Tensor]):
