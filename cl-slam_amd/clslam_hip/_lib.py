@@ -53,6 +53,7 @@ _SIGNATURES = {
     'clslam_wgrad_patch_splits': [C.POINTER(ConvDesc), i32],
     'clslam_conv_wgrad_patch': [C.POINTER(ConvDesc), fptr, fptr, i32, C.c_void_p],
     'clslam_reduce_partials': [fptr, fptr, C.c_size_t, i32, C.c_float, C.c_void_p],
+    'clslam_reduce_multi': [fptr, i32, i32, C.c_void_p],
     'clslam_colsum_blocks': [i32],
     'clslam_colsum': [fptr, fptr, i32, i32, C.c_void_p],
     'clslam_stem_conv': [fptr, fptr, fptr, fptr, fptr, fptr, i32, i32, i32, i32, C.c_void_p],

@@ -291,12 +291,8 @@ class Engine:
         t.dz_p1 = torch.empty_like(ws.p1)
         t.dz_p0 = torch.empty_like(ws.p0)
         t.dz_sq = torch.empty_like(ws.sq)
-        t.partial = None
-        t.partial_elems = 0
-        t.colsum = E(1024 * 256)
-        t.disp_part = E(512 * (9 * 128 + 1))
-        t.side = SimpleNamespace(partial=None, partial_elems=0, colsum=E(1024 * 256), wt=E(256 * 9 * 256))
-        t.wg = SimpleNamespace(partial=None, partial_elems=0, colsum=E(1024 * 256), disp_part=E(512 * (9 * 128 + 1)))
+        t.plan, t.items, t.table, t.disp_part = {}, [], None, {}
+        t.side = SimpleNamespace(wt=E(256 * 9 * 256))
         t.bias_part = {k: E(1024 * v.shape[-1]) for k, v in ws.x.items()}   # fused bias-grad partials per layer
         ws.train = t
         return t
@@ -475,27 +471,33 @@ class Engine:
     # backward
     def _wgrad(self, t, desc_src, out_shape, dz, name_prefix: str, cout: int, cin: int, taps: int, bias_blocks: int = 0,
                bias_partial=None, **geom) -> None:
-        """weight (+ bias) gradient of one conv into the gradient arena; bias_blocks > 0 means
-        bias_partial already holds that many per-block column sums of dz (fused into fold_act_grad)."""
+        """Weight (+ bias) gradient partials of one conv.  Every layer owns its partial buffers; the sums
+        into the gradient arena happen in ONE batched reduction at the end of backward()
+        (clslam_reduce_multi).  bias_blocks > 0: bias_partial already holds that many per-block column
+        sums of dz (fused into fold_act_grad)."""
         desc = ops.conv_desc(desc_src[0], out_shape, src_b=desc_src[1], ksize=3 if taps == 9 else 1, **geom)
-        use_patch = ops.wgrad_patch_supported(desc)
-        splits = ops.wgrad_patch_splits(desc, 512) if use_patch else ops.wgrad_splits(desc, 512)
         n = cout * taps * cin
-        if t.partial is None or t.partial_elems < splits * n:
-            t.partial_elems = max(splits * n, 64 * 1024 * 1024 // 4)
-            t.partial = torch.empty(t.partial_elems, device=self.device)
-        if use_patch:
-            ops.conv_wgrad_patch(desc, dz, t.partial, splits)
+        plan = t.plan.get(name_prefix)
+        if plan is None:
+            use_patch = ops.wgrad_patch_supported(desc)
+            splits = ops.wgrad_patch_splits(desc, 512) if use_patch else ops.wgrad_splits(desc, 512)
+            plan = SimpleNamespace(use_patch=use_patch, splits=splits, partial=torch.empty(splits * n, device=self.device),
+                                   colsum=None, nb=0)
+            t.items.append((plan.partial, self._slot(self.g, name_prefix + '.weight', n), n, splits))
+            if bias_blocks:
+                t.items.append((bias_partial, self._slot(self.g, name_prefix + '.bias', cout), cout, bias_blocks))
+            else:
+                rows = out_shape[0] * out_shape[1] * out_shape[2]
+                plan.nb = ops.colsum_blocks(rows)
+                plan.colsum = torch.empty(plan.nb * cout, device=self.device)
+                t.items.append((plan.colsum, self._slot(self.g, name_prefix + '.bias', cout), cout, plan.nb))
+            t.plan[name_prefix] = plan
+        if plan.use_patch:
+            ops.conv_wgrad_patch(desc, dz, plan.partial, plan.splits)
         else:
-            ops.conv_wgrad(desc, dz, t.partial, splits)
-        ops.reduce_partials(t.partial, self._slot(self.g, name_prefix + '.weight', n), n, splits)
-        if bias_blocks:
-            ops.reduce_partials(bias_partial, self._slot(self.g, name_prefix + '.bias', cout), cout, bias_blocks)
-            return
-        rows = out_shape[0] * out_shape[1] * out_shape[2]
-        nb = ops.colsum_blocks(rows)
-        ops.colsum(dz, t.colsum, rows, cout)
-        ops.reduce_partials(t.colsum, self._slot(self.g, name_prefix + '.bias', cout), cout, nb)
+            ops.conv_wgrad(desc, dz, plan.partial, plan.splits)
+        if plan.colsum is not None:
+            ops.colsum(dz, plan.colsum, out_shape[0] * out_shape[1] * out_shape[2], cout)
 
     def backward(self, B: int) -> None:
         """dL/d(trainable arena) for the last training forward; fills self.g (dpp.py:312)."""
@@ -522,6 +524,10 @@ class Engine:
         else:
             self._backward_depth_decoder(ws, t, B)
             self._backward_pose_decoder(ws, t, B, t)
+        # one batched, deterministic reduction of every weight / bias gradient partial into the arena
+        if t.table is None:
+            t.table = ops.make_reduce_table(t.items, self.device)
+        ops.reduce_multi(t.table, len(t.items), self.g)
 
     def _backward_depth_decoder(self, ws, t, B: int) -> None:
         """dgrad chain (critical path) on the current stream; every weight/bias gradient is independent
@@ -555,11 +561,13 @@ class Engine:
                 else:
                     ops.dispconv_bwd_data(t.dz_disp[i], wd.view(9, ci), dxp_in, ci, accumulate=True)
 
-                def disp_wgrad(i=i, hi=hi, wi=wi, ci=ci):   # dispconv weight + bias gradient
-                    nb = ops.dispconv_wgrad_blocks(B * hi * wi)
-                    ops.dispconv_wgrad(t.dz_disp[i], ws.x[i, 1], t.wg.disp_part)
-                    ops.reduce_partials(t.wg.disp_part, self._slot(self.g, f'depth_decoder/dispconv_{i}.conv.weight', 9 * ci + 1),
-                                        9 * ci + 1, nb)
+                def disp_wgrad(i=i, hi=hi, wi=wi, ci=ci):   # dispconv weight + bias gradient partials
+                    if i not in t.disp_part:
+                        nb = ops.dispconv_wgrad_blocks(B * hi * wi)
+                        t.disp_part[i] = torch.empty(nb * (9 * ci + 1), device=self.device)
+                        t.items.append((t.disp_part[i], self._slot(self.g, f'depth_decoder/dispconv_{i}.conv.weight', 9 * ci + 1),
+                                        9 * ci + 1, nb))
+                    ops.dispconv_wgrad(t.dz_disp[i], ws.x[i, 1], t.disp_part[i])
                 on_wg(disp_wgrad)
             nb1 = ops.fold_blocks(B, hi, wi, ci, False)
             ops.fold_act_grad(dxp_in, ws.x[i, 1], t.dz[i, 1], h=hi, w=wi, ch=ci, border=1, pool=False, act=ACT_ELU,
@@ -568,7 +576,7 @@ class Engine:
             skip = feats[i - 1] if i > 0 else None
             cin1 = ci + (NUM_CH_ENC[i - 1] if i > 0 else 0)
             on_wg(lambda i=i, hi=hi, wi=wi, ci=ci, skip=skip, cin1=cin1, nb1=nb1: self._wgrad(
-                t.wg, (ws.x[i, 0], skip), (B, hi, wi, ci), t.dz[i, 1], f'depth_decoder/upconv_{i}_1.conv.conv', ci, cin1, 9,
+                t, (ws.x[i, 0], skip), (B, hi, wi, ci), t.dz[i, 1], f'depth_decoder/upconv_{i}_1.conv.conv', ci, cin1, 9,
                 bias_blocks=nb1, bias_partial=t.bias_part[i, 1], pad_mode=PAD_REFLECT, upsample_a=True))
             w1, _ = self._wb(f'depth_decoder/upconv_{i}_1.conv.conv', ci, cin1, 9)
             wt = t.wt[:ci * 9 * ci].view(ci, 9, ci)
@@ -583,7 +591,7 @@ class Engine:
             cin0 = NUM_CH_ENC[-1] if i == 4 else NUM_CH_DEC[i + 1]
             h2, w2 = hi >> 1, wi >> 1
             on_wg(lambda i=i, h2=h2, w2=w2, ci=ci, src=src, cin0=cin0, nb0=nb0: self._wgrad(
-                t.wg, (src, None), (B, h2, w2, ci), t.dz[i, 0], f'depth_decoder/upconv_{i}_0.conv.conv', ci, cin0, 9,
+                t, (src, None), (B, h2, w2, ci), t.dz[i, 0], f'depth_decoder/upconv_{i}_0.conv.conv', ci, cin0, 9,
                 bias_blocks=nb0, bias_partial=t.bias_part[i, 0], pad_mode=PAD_REFLECT))
             if i < 4:
                 w0, _ = self._wb(f'depth_decoder/upconv_{i}_0.conv.conv', ci, cin0, 9)
@@ -604,16 +612,16 @@ class Engine:
         ops.pose_head_bwd(t.dpose, ws.p1, w2_.view(12, 256), ws.pmean, t.dz_p1,
                           self._slot(self.g, 'pose_decoder/pose_2.weight', 12 * 256).view(12, 256),
                           self._slot(self.g, 'pose_decoder/pose_2.bias', 12))
-        self._wgrad(scratch, (ws.p0, None), (n2, h5, w5, 256), t.dz_p1, 'pose_decoder/pose_1', 256, 256, 9)
+        self._wgrad(t, (ws.p0, None), (n2, h5, w5, 256), t.dz_p1, 'pose_decoder/pose_1', 256, 256, 9)
         wp1, _ = self._wb('pose_decoder/pose_1', 256, 256, 9)
         wt = scratch.wt[:256 * 9 * 256].view(256, 9, 256)
         ops.weight_transpose(wp1, wt)
         ops.conv2d(t.dz_p1, wt, t.dz_p0, ksize=3, pad=1, actgrad_src=ws.p0, actgrad_kind=ACT_RELU)
-        self._wgrad(scratch, (ws.sq, None), (n2, h5, w5, 256), t.dz_p0, 'pose_decoder/pose_0', 256, 256, 9)
+        self._wgrad(t, (ws.sq, None), (n2, h5, w5, 256), t.dz_p0, 'pose_decoder/pose_0', 256, 256, 9)
         wp0, _ = self._wb('pose_decoder/pose_0', 256, 256, 9)
         ops.weight_transpose(wp0, wt)
         ops.conv2d(t.dz_p0, wt, t.dz_sq, ksize=3, pad=1, actgrad_src=ws.sq, actgrad_kind=ACT_RELU)
-        self._wgrad(scratch, (ws.pf4, None), (n2, h5, w5, 256), t.dz_sq, 'pose_decoder/squeeze', 256, 512, 1, pad=0)
+        self._wgrad(t, (ws.pf4, None), (n2, h5, w5, 256), t.dz_sq, 'pose_decoder/squeeze', 256, 512, 1, pad=0)
 
     # ------------------------------------------------------------------------------------------
     # hipGraph: the whole forward+backward of a training step is ~230 kernel launches over three

@@ -125,6 +125,19 @@ def reduce_partials(partial, out, n, splits, scale=1.0):
     return out
 
 
+def make_reduce_table(items, device):
+    """items: list of (partial tensor, out tensor, n, splits) -> device byte tensor for reduce_multi"""
+    import numpy as np
+    rec = np.zeros(len(items), dtype=np.dtype([('partial', '<u8'), ('out', '<u8'), ('n', '<u8'), ('splits', '<i4'), ('scale', '<f4')]))
+    for i, (part, out, n, splits) in enumerate(items):
+        rec[i] = (_p(part), _p(out), n, splits, 1.0)
+    return torch.from_numpy(rec.view(np.uint8).copy()).to(device)
+
+
+def reduce_multi(table, nitems, stream_ref, blocks_per_item=64):
+    _lib.get_lib().call('clslam_reduce_multi', table.data_ptr(), nitems, blocks_per_item, _stream(stream_ref))
+
+
 def colsum_blocks(rows: int) -> int:
     return _lib.get_lib().cdll.clslam_colsum_blocks(rows)
 

@@ -274,6 +274,27 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
     }
 }
 
+// Batched form: one launch reduces a whole table of (partial, out, n, splits) items (all the weight /
+// bias gradients of a step); blockIdx.y = item, blockIdx.x strides over the item's outputs.
+struct ReduceItem { const float* partial; float* out; unsigned long long n; int splits; float scale; };
+
+__global__ __launch_bounds__(256) void reduce_multi_kernel(const ReduceItem* __restrict__ items) {
+    constexpr int IL = 64, KL = 4;
+    __shared__ float red[256];
+    const ReduceItem it = items[blockIdx.y];
+    const int il = threadIdx.x % IL, kl = threadIdx.x / IL;
+    for (size_t i0 = (size_t)blockIdx.x * IL; i0 < it.n; i0 += (size_t)gridDim.x * IL) {
+        const size_t i = i0 + il;
+        float s = 0.f;
+        if (i < it.n)
+            for (int k = kl; k < it.splits; k += KL) s += it.partial[(size_t)k * it.n + i];
+        red[threadIdx.x] = s;
+        __syncthreads();
+        if (kl == 0 && i < it.n) it.out[i] = (red[il] + red[IL + il] + red[2 * IL + il] + red[3 * IL + il]) * it.scale;
+        __syncthreads();
+    }
+}
+
 // partial[blk][c] = sum over the block's rows of x[row][c]
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, float* __restrict__ partial,
                                                      int M, int C, int rows_per_block) {
@@ -385,6 +406,17 @@ extern "C" int clslam_reduce_partials(const float* partial, float* out, size_t n
         hipLaunchKernelGGL(reduce_partials_kernel<16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, partial, out, n, splits, scale);
     }
     return check_launch("reduce_partials");
+}
+
+// items_dev: device array of nitems {const float* partial; float* out; uint64 n; int32 splits; float scale}
+// (32 bytes each).  One launch for all of a step's gradient reductions.
+extern "C" int clslam_reduce_multi(const void* items_dev, int nitems, int blocks_per_item, void* stream) {
+    CLSLAM_REQUIRE(items_dev && nitems >= 0 && blocks_per_item >= 1, "reduce_multi: bad args");
+    static_assert(sizeof(ReduceItem) == 32, "ReduceItem layout");
+    if (!nitems) return CLSLAM_OK;
+    hipLaunchKernelGGL(reduce_multi_kernel, dim3(blocks_per_item, nitems), dim3(256), 0, (hipStream_t)stream,
+                       (const ReduceItem*)items_dev);
+    return check_launch("reduce_multi");
 }
 
 extern "C" int clslam_colsum_blocks(int rows) { return std::max(1, std::min(512, cdiv(rows, 16))); }

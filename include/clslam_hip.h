@@ -104,6 +104,9 @@ int clslam_wgrad_patch_splits(const clslam_conv_desc* desc, int target_blocks);
 int clslam_conv_wgrad_patch(const clslam_conv_desc* desc, const float* dz, float* partial, int splits, void* stream);
 /* out[i] = scale * sum_s partial[s*n + i] in a fixed order (deterministic).                    */
 int clslam_reduce_partials(const float* partial, float* out, size_t n, int splits, float scale, void* stream);
+/* Batched clslam_reduce_partials: items_dev is a DEVICE array of nitems records
+ * {const float* partial; float* out; uint64_t n; int32_t splits; float scale} (32 bytes each).     */
+int clslam_reduce_multi(const void* items_dev, int nitems, int blocks_per_item, void* stream);
 /* bias gradient: column sums of x[rows][ch], stage 1 (follow with clslam_reduce_partials).     */
 int clslam_colsum_blocks(int rows);
 int clslam_colsum(const float* x, float* partial, int rows, int ch, void* stream);
