@@ -278,9 +278,8 @@ class Engine:
         E = lambda *s: torch.empty(*s, device=dev)  # noqa: E731
         t = SimpleNamespace()
         ws.coef = E(4, 2, B, 9, H, W)
-        t.dpred = E(2, B, 3, H, W)
-        t.ddisp_up = E(B, H, W)
-        t.nb2 = ops.warp_bwd_blocks(H, W)
+        t.ddisp_up = E(4, B, H, W)
+        t.nb2 = ops.loss_bwd_blocks(H, W)
         t.dp_partial = E(4, B, t.nb2, 24)
         t.dz_disp = [torch.empty(B, H >> s, W >> s, device=dev) for s in range(4)]
         t.dpose = E(2 * B, 12)
@@ -393,8 +392,7 @@ class Engine:
         K = self._mat(inputs['camera_matrix', 0])
         Kinv = self._mat(inputs['inv_camera_matrix', 0])
         ops.pose_to_proj(ws.pose, K, ws.T, ws.P)
-        for s in range(4):
-            ops.warp_fwd(ws.disp[s], rgb[-1], rgb[1], Kinv, ws.P, ws.depth[s], ws.warped[s], self.min_depth, self.max_depth)
+        ops.warp_fwd_pyramid(ws.disp, rgb[-1], rgb[1], Kinv, ws.P, ws.depth, ws.warped, self.min_depth, self.max_depth)
         ws.idsrc[0].copy_(rgb[-1])
         ws.idsrc[1].copy_(rgb[1])
         ops.photo_map(ws.idsrc, rgb[0], ws.idmap, None, 2 * B, B, H, W)
@@ -409,10 +407,10 @@ class Engine:
             have_noise = True
         else:
             have_noise = False
-        for s in range(4):
-            ops.photo_map(ws.warped[s], rgb[0], ws.rpmap[s], ws.coef[s] if train else None, 2 * B, B, H, W)
-            ops.automask(ws.idmap, ws.noise[s] if have_noise else None, ws.rpmap[s], ws.sel[s], ws.partial[s], B, H, W)
-            ops.disp_mean(ws.disp[s], ws.means[s])
+        # the four scales are contiguous along the leading dim: one launch each (8B "images" vs target n % B)
+        ops.photo_map(ws.warped, rgb[0], ws.rpmap, ws.coef if train else None, 8 * B, B, H, W)
+        ops.automask_pyramid(ws.idmap, ws.noise if have_noise else None, ws.rpmap, ws.sel, ws.partial, B, H, W)
+        ops.disp_mean_pyramid(ws.disp, ws.means, H, W)
         n_smooth = 0 if smooth_w is None else int(smooth_w.numel())
         if n_smooth and not (n_smooth < (W >> 3) - 1):
             raise ClslamError('reference smoothness layout needs batch < width/8 - 1')
@@ -507,11 +505,9 @@ class Engine:
         H, W = self.H, self.W
         feats = ws.dfeats
         # loss -> disparity logits and pose-decoder output ----------------------------------------
-        for s in range(4):
-            ops.photo_grad(ws.sel[s], ws.coef[s], ws.warped[s], c.rgb[0], c.sample_w, t.dpred, B, H, W)
-            ops.warp_bwd(t.dpred, ws.disp[s], c.rgb[-1], c.rgb[1], c.Kinv, ws.P, t.ddisp_up, t.dp_partial[s], self.min_depth,
-                         self.max_depth)
-            ops.disp_grad(t.ddisp_up, ws.disp[s], c.aux[s] if c.n_smooth else None, c.n_smooth, t.dz_disp[s], H, W)
+        ops.loss_bwd_pyramid(ws.disp, ws.sel, ws.coef, ws.warped, c.rgb[0], c.rgb[-1], c.rgb[1], c.Kinv, ws.P, c.sample_w,
+                             t.ddisp_up, t.dp_partial, self.min_depth, self.max_depth)
+        ops.disp_grad_pyramid(t.ddisp_up, ws.disp, c.aux if c.n_smooth else None, c.n_smooth, t.dz_disp, H, W)
         ops.pose_bwd(t.dp_partial, 4, t.nb2, ws.pose, c.K, c.d0, c.d1, c.sample_w, self.vel_scale, t.dpose)
         side = self.side_stream if (self.use_side_stream and self.side_stream is not None) else None
         if side is not None:

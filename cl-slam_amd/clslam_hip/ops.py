@@ -312,3 +312,40 @@ def channel_scale(x, gate):
     B, Cc = x.shape[0], x.shape[-1]
     _lib.get_lib().call('clslam_channel_scale', _p(x), _p(gate), B, x.numel() // (B * Cc), Cc, _stream(x))
     return x
+
+
+# ---- pyramid forms: one launch for the four scales -----------------------------------------------------
+def _ptr4(tensors):
+    return (C.c_void_p * 4)(*[_p(t) for t in tensors])
+
+
+def warp_fwd_pyramid(disps, src_m1, src_p1, inv_k, proj, depth, warped, min_depth, max_depth):
+    B, H, W = depth.shape[1], depth.shape[-2], depth.shape[-1]
+    _lib.get_lib().call('clslam_warp_fwd_pyramid', _ptr4(disps), _p(src_m1), _p(src_p1), _p(inv_k), _p(proj), _p(depth),
+                        _p(warped), B, H, W, _nd(min_depth), _nd(max_depth), _stream(depth))
+
+
+def automask_pyramid(idmap, noise, rpmap, sel, partial, batch, H, W):
+    _lib.get_lib().call('clslam_automask_pyramid', _p(idmap), _p(noise), _p(rpmap), _pa(sel, torch.uint8), _p(partial), 4,
+                        batch, H, W, _stream(idmap))
+
+
+def disp_mean_pyramid(disps, means, H, W):
+    _lib.get_lib().call('clslam_disp_mean_pyramid', _ptr4(disps), _p(means), disps[0].shape[0], H, W, _stream(means))
+
+
+def loss_bwd_blocks(H, W) -> int:
+    return _lib.get_lib().cdll.clslam_loss_bwd_blocks(H, W)
+
+
+def loss_bwd_pyramid(disps, sel, coef, warped, target, src_m1, src_p1, inv_k, proj, sample_w, ddisp_up, dp_partial,
+                     min_depth, max_depth):
+    B, H, W = ddisp_up.shape[1], ddisp_up.shape[-2], ddisp_up.shape[-1]
+    _lib.get_lib().call('clslam_loss_bwd_pyramid', _ptr4(disps), _pa(sel, torch.uint8), _p(coef), _p(warped), _p(target),
+                        _p(src_m1), _p(src_p1), _p(inv_k), _p(proj), _p(sample_w), _p(ddisp_up), _p(dp_partial), B, H, W,
+                        _nd(min_depth), _nd(max_depth), _stream(ddisp_up))
+
+
+def disp_grad_pyramid(ddisp_up, disps, smooth_aux, n_smooth, dzs, H, W):
+    _lib.get_lib().call('clslam_disp_grad_pyramid', _p(ddisp_up), _ptr4(disps), _p(smooth_aux), n_smooth, _ptr4(dzs),
+                        disps[0].shape[0], H, W, _stream(ddisp_up))

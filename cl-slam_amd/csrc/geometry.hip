@@ -7,6 +7,7 @@
 // scale-0 intrinsics).  All of it is HBM-bound per-pixel work: one thread per pixel, planar NCHW
 // images exactly as the reference's sample/output dicts hold them, coalesced along x.
 #include "common.h"
+#include "geometry_dev.h"
 
 namespace clslam {
 
@@ -58,63 +59,22 @@ __global__ void pose_to_proj_kernel(const float* __restrict__ pose, const float*
 }
 
 // ------------------------------------------------------------------------------------------------
-struct WarpGeom {
-    float depth, disp, u, v;          // forward values
-    float X[3];                       // back-projected point
-    float cam[3];                     // Kinv[:3,:3] * [x,y,1]
-};
-
-__device__ __forceinline__ float upsample_disp(const float* __restrict__ d, int h, int w, int H, int W, int y, int x) {
-    // F.interpolate(..., mode='bilinear', align_corners=False): src = (dst+0.5)*in/out - 0.5, clamped at 0
-    const float ry = (float)h / (float)H, rx = (float)w / (float)W;
-    float sy = ry * ((float)y + 0.5f) - 0.5f; if (sy < 0.f) sy = 0.f;
-    float sx = rx * ((float)x + 0.5f) - 0.5f; if (sx < 0.f) sx = 0.f;
-    const int y0 = (int)sy, x0 = (int)sx;
-    const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
-    const float ly = sy - (float)y0, lx = sx - (float)x0;
-    const float hy = 1.f - ly, hx = 1.f - lx;
-    return hy * (hx * d[y0 * w + x0] + lx * d[y0 * w + x1]) + ly * (hx * d[y1 * w + x0] + lx * d[y1 * w + x1]);
-}
-
-__device__ __forceinline__ float disp_to_depth_dev(float disp, float dmin_a, float dmin_b, int mode) {
-    // mode 0: 1/disp; 1: min_depth/disp (a = min_depth); 2: 1/(a + b*disp) (a = 1/max, b = 1/min - 1/max)
-    if (mode == 0) return 1.f / disp;
-    if (mode == 1) return dmin_a / disp;
-    return 1.f / (dmin_a + dmin_b * disp);
-}
-
-struct Sample {
-    float ix, iy;       // clipped pixel coordinates
-    float mx, my;       // gradient multipliers of the clip (0 at / outside the border)
-    int x0, y0;         // floor
-};
-
-__device__ __forceinline__ Sample sample_coords(float u, float v, int H, int W) {
-    // Project3D normalisation (layers.py:101-103) followed by grid_sample's un-normalisation
-    // (align_corners=True) and border clipping.
-    Sample s;
-    const float gx = (u / (float)(W - 1) - 0.5f) * 2.f;
-    const float gy = (v / (float)(H - 1) - 0.5f) * 2.f;
-    float ix = ((gx + 1.f) / 2.f) * (float)(W - 1);
-    float iy = ((gy + 1.f) / 2.f) * (float)(H - 1);
-    s.mx = 1.f; s.my = 1.f;
-    if (!(ix > 0.f)) { ix = 0.f; s.mx = 0.f; } else if (ix >= (float)(W - 1)) { ix = (float)(W - 1); s.mx = 0.f; }
-    if (!(iy > 0.f)) { iy = 0.f; s.my = 0.f; } else if (iy >= (float)(H - 1)) { iy = (float)(H - 1); s.my = 0.f; }
-    s.ix = ix; s.iy = iy;
-    s.x0 = (int)floorf(ix); s.y0 = (int)floorf(iy);
-    return s;
-}
-
-// depth[b,y,x] and warped[fi,b,c,y,x] for one scale.
-__global__ __launch_bounds__(256) void warp_fwd_kernel(const float* __restrict__ disp_s, int h, int w,
-                                                       const float* __restrict__ src_m1, const float* __restrict__ src_p1,
-                                                       const float* __restrict__ Kinv, const float* __restrict__ P,
-                                                       float* __restrict__ depth, float* __restrict__ warped, int B, int H,
-                                                       int W, float da, float db, int dmode) {
-    const size_t total = (size_t)B * H * W;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+// depth[s,b,y,x] and warped[s,fi,b,c,y,x] for the pyr.n scales of a pyramid (one launch).
+__global__ __launch_bounds__(256) void warp_fwd_kernel(Pyramid pyr, const float* __restrict__ src_m1,
+                                                       const float* __restrict__ src_p1, const float* __restrict__ Kinv,
+                                                       const float* __restrict__ P, float* __restrict__ depth_all,
+                                                       float* __restrict__ warped_all, int B, int H, int W, float da, float db,
+                                                       int dmode) {
+    const size_t per = (size_t)B * H * W;
+    const size_t total = per * pyr.n;
+    for (size_t gidx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; gidx < total; gidx += (size_t)gridDim.x * blockDim.x) {
+        const int sc = (int)(gidx / per);
+        const size_t idx = gidx - (size_t)sc * per;
+        const int h = pyr.h[sc], w = pyr.w[sc];
+        float* depth = depth_all + (size_t)sc * per;
+        float* warped = warped_all + (size_t)sc * per * 6;
         const int x = (int)(idx % W), y = (int)((idx / W) % H), b = (int)(idx / ((size_t)W * H));
-        const float disp = upsample_disp(disp_s + (size_t)b * h * w, h, w, H, W, y, x);
+        const float disp = upsample_disp(pyr.disp[sc] + (size_t)b * h * w, h, w, H, W, y, x);
         const float dep = disp_to_depth_dev(disp, da, db, dmode);
         depth[idx] = dep;
         const float* Ki = Kinv + (size_t)b * 16;
@@ -323,13 +283,6 @@ __global__ __launch_bounds__(256) void pose_bwd_kernel(const float* __restrict__
 
 using namespace clslam;
 
-static void depth_mode(float min_depth, float max_depth, float* a, float* b, int* mode) {
-    // utils.py:120-142 ; a value <= 0 stands for None
-    if (min_depth <= 0.f && max_depth <= 0.f) { *mode = 0; *a = 0.f; *b = 0.f; }
-    else if (max_depth <= 0.f) { *mode = 1; *a = min_depth; *b = 0.f; }
-    else { *mode = 2; *a = 1.f / max_depth; *b = 1.f / min_depth - 1.f / max_depth; }
-}
-
 extern "C" int clslam_pose_to_proj(const float* pose, const float* kmat, float* cam_t_cam, float* proj, int batch,
                                    void* stream) {
     CLSLAM_REQUIRE(pose && kmat && cam_t_cam && proj, "pose_to_proj: null");
@@ -348,9 +301,30 @@ extern "C" int clslam_warp_fwd(const float* disp_s, int h, int w, const float* s
     depth_mode(min_depth, max_depth, &a, &b, &mode);
     const size_t total = (size_t)batch * H * W;
     if (!total) return CLSLAM_OK;
+    Pyramid pyr;
+    pyr.n = 1; pyr.disp[0] = disp_s; pyr.h[0] = h; pyr.w[0] = w;
+    for (int k = 1; k < 4; ++k) { pyr.disp[k] = nullptr; pyr.h[k] = pyr.w[k] = 0; }
     hipLaunchKernelGGL(warp_fwd_kernel, dim3((unsigned)std::min<size_t>(8192, (total + 255) / 256)), dim3(256), 0,
-                       (hipStream_t)stream, disp_s, h, w, src_m1, src_p1, inv_k, proj, depth, warped, batch, H, W, a, b, mode);
+                       (hipStream_t)stream, pyr, src_m1, src_p1, inv_k, proj, depth, warped, batch, H, W, a, b, mode);
     return check_launch("warp_fwd");
+}
+
+// All four scales in one launch: disp[s] (B,H>>s,W>>s); depth (4,B,H,W); warped (4,2,B,3,H,W).
+extern "C" int clslam_warp_fwd_pyramid(const float* const* disp, const float* src_m1, const float* src_p1, const float* inv_k,
+                                       const float* proj, float* depth, float* warped, int batch, int H, int W,
+                                       float min_depth, float max_depth, void* stream) {
+    CLSLAM_REQUIRE(disp && src_m1 && src_p1 && inv_k && proj && depth && warped, "warp_fwd_pyramid: null");
+    CLSLAM_REQUIRE(!(min_depth <= 0.f && max_depth > 0.f), "warp_fwd_pyramid: min_depth is None");
+    float a, b; int mode;
+    depth_mode(min_depth, max_depth, &a, &b, &mode);
+    Pyramid pyr;
+    pyr.n = 4;
+    for (int k = 0; k < 4; ++k) { pyr.disp[k] = disp[k]; pyr.h[k] = H >> k; pyr.w[k] = W >> k; }
+    const size_t total = (size_t)4 * batch * H * W;
+    if (!total) return CLSLAM_OK;
+    hipLaunchKernelGGL(warp_fwd_kernel, dim3((unsigned)std::min<size_t>(16384, (total + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, pyr, src_m1, src_p1, inv_k, proj, depth, warped, batch, H, W, a, b, mode);
+    return check_launch("warp_fwd_pyramid");
 }
 
 extern "C" int clslam_warp_bwd_blocks(int H, int W) { return std::max(1, std::min(256, cdiv(H * W, 1024))); }

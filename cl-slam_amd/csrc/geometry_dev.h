@@ -1,0 +1,65 @@
+// Device helpers shared by geometry.hip and loss.hip: bilinear disparity upsampling, disp->depth,
+// projected-pixel -> sampling coordinates (reference dpp.py:988-995, utils.py:120-142,
+// networks/layers.py:93-104 + F.grid_sample(border, align_corners=True)).
+#pragma once
+#include "common.h"
+
+namespace clslam {
+
+// up to four disparity maps of a pyramid (scale s has h[s] x w[s] pixels, batch-major)
+struct Pyramid {
+    const float* disp[4];
+    int h[4], w[4];
+    int n;
+};
+
+__device__ __forceinline__ float upsample_disp(const float* __restrict__ d, int h, int w, int H, int W, int y, int x) {
+    // F.interpolate(..., mode='bilinear', align_corners=False): src = (dst+0.5)*in/out - 0.5, clamped at 0
+    const float ry = (float)h / (float)H, rx = (float)w / (float)W;
+    float sy = ry * ((float)y + 0.5f) - 0.5f; if (sy < 0.f) sy = 0.f;
+    float sx = rx * ((float)x + 0.5f) - 0.5f; if (sx < 0.f) sx = 0.f;
+    const int y0 = (int)sy, x0 = (int)sx;
+    const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
+    const float ly = sy - (float)y0, lx = sx - (float)x0;
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    return hy * (hx * d[y0 * w + x0] + lx * d[y0 * w + x1]) + ly * (hx * d[y1 * w + x0] + lx * d[y1 * w + x1]);
+}
+
+__device__ __forceinline__ float disp_to_depth_dev(float disp, float dmin_a, float dmin_b, int mode) {
+    // mode 0: 1/disp; 1: min_depth/disp (a = min_depth); 2: 1/(a + b*disp) (a = 1/max, b = 1/min - 1/max)
+    if (mode == 0) return 1.f / disp;
+    if (mode == 1) return dmin_a / disp;
+    return 1.f / (dmin_a + dmin_b * disp);
+}
+
+struct Sample {
+    float ix, iy;       // clipped pixel coordinates
+    float mx, my;       // gradient multipliers of the clip (0 at / outside the border)
+    int x0, y0;         // floor
+};
+
+__device__ __forceinline__ Sample sample_coords(float u, float v, int H, int W) {
+    // Project3D normalisation (layers.py:101-103) followed by grid_sample's un-normalisation
+    // (align_corners=True) and border clipping.
+    Sample s;
+    const float gx = (u / (float)(W - 1) - 0.5f) * 2.f;
+    const float gy = (v / (float)(H - 1) - 0.5f) * 2.f;
+    float ix = ((gx + 1.f) / 2.f) * (float)(W - 1);
+    float iy = ((gy + 1.f) / 2.f) * (float)(H - 1);
+    s.mx = 1.f; s.my = 1.f;
+    if (!(ix > 0.f)) { ix = 0.f; s.mx = 0.f; } else if (ix >= (float)(W - 1)) { ix = (float)(W - 1); s.mx = 0.f; }
+    if (!(iy > 0.f)) { iy = 0.f; s.my = 0.f; } else if (iy >= (float)(H - 1)) { iy = (float)(H - 1); s.my = 0.f; }
+    s.ix = ix; s.iy = iy;
+    s.x0 = (int)floorf(ix); s.y0 = (int)floorf(iy);
+    return s;
+}
+
+
+// mode/a/b of disp_to_depth_dev from (min_depth, max_depth); values <= 0 stand for None (utils.py:120-142)
+inline void depth_mode(float min_depth, float max_depth, float* a, float* b, int* mode) {
+    if (min_depth <= 0.f && max_depth <= 0.f) { *mode = 0; *a = 0.f; *b = 0.f; }
+    else if (max_depth <= 0.f) { *mode = 1; *a = min_depth; *b = 0.f; }
+    else { *mode = 2; *a = 1.f / max_depth; *b = 1.f / min_depth - 1.f / max_depth; }
+}
+
+}  // namespace clslam

@@ -10,6 +10,7 @@
 // element i of sample 0's gradient maps -- SURVEY.md 0.3), dpp.py:1105-1112 and 1125-1146
 // (velocity), autograd for the backward.  HBM-bound stencil / pointwise kernels on planar images.
 #include "common.h"
+#include "geometry_dev.h"
 
 namespace clslam {
 
@@ -67,11 +68,18 @@ __global__ __launch_bounds__(256) void photo_map_kernel(const float* __restrict_
 // ------------------------------------------------------------------------------------------------
 // to_optimize = min over [id(-1)+noise0, id(+1)+noise1, reproj(-1), reproj(+1)]; sel = argmin;
 // partial[b][blk] = block sum of to_optimize.  grid (nblk, B).
-__global__ __launch_bounds__(256) void automask_kernel(const float* __restrict__ idmap, const float* __restrict__ noise,
-                                                       const float* __restrict__ rpmap, unsigned char* __restrict__ sel,
-                                                       float* __restrict__ partial, int B, int HW, int pix_per_block) {
+__global__ __launch_bounds__(256) void automask_kernel(const float* __restrict__ idmap, const float* noise,
+                                                       const float* rpmap, unsigned char* sel, float* partial, int B,
+                                                       int HW, int pix_per_block) {
     __shared__ float red[4];
     const int b = blockIdx.y;
+    {   // blockIdx.z = scale of the pyramid: per-scale slices of noise / rpmap / sel / partial
+        const size_t sc = blockIdx.z;
+        if (noise) noise += sc * (size_t)B * 2 * HW;
+        rpmap += sc * (size_t)2 * B * HW;
+        sel += sc * (size_t)B * HW;
+        partial += sc * (size_t)B * gridDim.x;
+    }
     const int p0 = blockIdx.x * pix_per_block, p1 = min(HW, p0 + pix_per_block);
     float s = 0.f;
     for (int p = p0 + (int)threadIdx.x; p < p1; p += 256) {
@@ -96,9 +104,13 @@ __global__ __launch_bounds__(256) void automask_kernel(const float* __restrict__
 // per-sample disparity sums in DM_CHUNKS pieces: psum[b][chunk] (grid (DM_CHUNKS, B)); the finalize
 // kernel adds the chunks in order and divides by h*w.
 constexpr int DM_CHUNKS = 32;
-__global__ __launch_bounds__(256) void disp_mean_kernel(const float* __restrict__ disp, float* __restrict__ psum, int hw) {
+__global__ __launch_bounds__(256) void disp_mean_kernel(Pyramid pyr, float* psum, int B) {
     __shared__ float red[4];
     const int b = blockIdx.y;
+    const int sc = blockIdx.z;
+    const float* disp = pyr.disp[sc];
+    const int hw = pyr.h[sc] * pyr.w[sc];
+    psum += (size_t)sc * B * DM_CHUNKS;
     const int per = (hw + DM_CHUNKS - 1) / DM_CHUNKS;
     const int p0 = blockIdx.x * per, p1 = min(hw, p0 + per);
     float s = 0.f;
@@ -223,8 +235,45 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(FinalizeArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// dpred[fi,b,c,y,x] = dL/d warped for one scale: transposed SSIM stencil over the pixels whose
-// min picked reprojection fi (sel == 2+fi), reflection fold, plus the L1 term.
+// dL/d warped[n = fi*B+b][c][y][x] (un-weighted) for one scale: transposed SSIM stencil over the pixels
+// whose min picked reprojection fi (sel == 2+fi), reflection fold, plus the L1 term.
+__device__ __forceinline__ void photo_grad_px(const unsigned char* __restrict__ sl, const float* __restrict__ coef_n,
+                                              const float* __restrict__ pred_n, const float* __restrict__ target_b, int H,
+                                              int W, int y, int x, unsigned char want, float g[3]) {
+    const size_t HW = (size_t)H * W;
+    int py[3], px[3], npy = 0, npx = 0;   // padded-domain positions that reflect onto (y,x)
+    py[npy++] = y + 1; px[npx++] = x + 1;
+    if (y == 1) py[npy++] = 0;
+    if (y == H - 2) py[npy++] = H + 1;
+    if (x == 1) px[npx++] = 0;
+    if (x == W - 2) px[npx++] = W + 1;
+    float sa[3] = {0.f, 0.f, 0.f}, sb[3] = {0.f, 0.f, 0.f}, sc[3] = {0.f, 0.f, 0.f};
+    for (int iy = 0; iy < npy; ++iy)
+        for (int ix = 0; ix < npx; ++ix) {
+            const int qy0 = max(0, py[iy] - 2), qy1 = min(H - 1, py[iy]);
+            const int qx0 = max(0, px[ix] - 2), qx1 = min(W - 1, px[ix]);
+            for (int qy = qy0; qy <= qy1; ++qy)
+                for (int qx = qx0; qx <= qx1; ++qx) {
+                    if (sl[qy * W + qx] != want) continue;
+                    const float* co = coef_n + (size_t)qy * W + qx;
+                    for (int c = 0; c < 3; ++c) {
+                        sa[c] += co[(c * 3 + 0) * HW];
+                        sb[c] += co[(c * 3 + 1) * HW];
+                        sc[c] += co[(c * 3 + 2) * HW];
+                    }
+                }
+        }
+    const bool own = sl[y * W + x] == want;
+    for (int c = 0; c < 3; ++c) {
+        const float xv = pred_n[(size_t)c * HW + (size_t)y * W + x];
+        const float yv = target_b[(size_t)c * HW + (size_t)y * W + x];
+        float v = sa[c] + sb[c] * xv + sc[c] * yv;
+        if (own) v += (0.15f / 3.f) * (xv > yv ? 1.f : (xv < yv ? -1.f : 0.f));
+        g[c] = v;
+    }
+}
+
+// dpred[fi,b,c,y,x] = dL/d warped for one scale (stand-alone form, used by the kernel-level tests)
 __global__ __launch_bounds__(256) void photo_grad_kernel(const unsigned char* __restrict__ sel, const float* __restrict__ coef,
                                                          const float* __restrict__ pred, const float* __restrict__ target,
                                                          const float* __restrict__ sample_w, float* __restrict__ dpred,
@@ -236,48 +285,115 @@ __global__ __launch_bounds__(256) void photo_grad_kernel(const unsigned char* __
         const int x = (int)(idx % W), y = (int)((idx / W) % H);
         const int n = (int)(idx / HW);  // fi*B + b
         const int fi = n / B, b = n - fi * B;
-        const unsigned char want = (unsigned char)(2 + fi);
-        const unsigned char* sl = sel + (size_t)b * HW;
-        // padded-domain positions that reflect onto (y,x)
-        int py[3], px[3], npy = 0, npx = 0;
-        py[npy++] = y + 1; px[npx++] = x + 1;
-        if (y == 1) py[npy++] = 0;
-        if (y == H - 2) py[npy++] = H + 1;
-        if (x == 1) px[npx++] = 0;
-        if (x == W - 2) px[npx++] = W + 1;
-        float sa[3] = {0.f, 0.f, 0.f}, sb[3] = {0.f, 0.f, 0.f}, sc[3] = {0.f, 0.f, 0.f};
-        for (int iy = 0; iy < npy; ++iy)
-            for (int ix = 0; ix < npx; ++ix) {
-                const int qy0 = max(0, py[iy] - 2), qy1 = min(H - 1, py[iy]);
-                const int qx0 = max(0, px[ix] - 2), qx1 = min(W - 1, px[ix]);
-                for (int qy = qy0; qy <= qy1; ++qy)
-                    for (int qx = qx0; qx <= qx1; ++qx) {
-                        if (sl[qy * W + qx] != want) continue;
-                        const float* co = coef + (size_t)n * 9 * HW + (size_t)qy * W + qx;
-                        for (int c = 0; c < 3; ++c) {
-                            sa[c] += co[(c * 3 + 0) * HW];
-                            sb[c] += co[(c * 3 + 1) * HW];
-                            sc[c] += co[(c * 3 + 2) * HW];
-                        }
-                    }
-            }
+        float g[3];
+        photo_grad_px(sel + (size_t)b * HW, coef + (size_t)n * 9 * HW, pred + (size_t)n * 3 * HW, target + (size_t)b * 3 * HW, H, W,
+                      y, x, (unsigned char)(2 + fi), g);
         const float wq = sample_w[b] * scale_all;
-        const bool own = sl[y * W + x] == want;
-        for (int c = 0; c < 3; ++c) {
-            const float xv = pred[((size_t)n * 3 + c) * HW + (size_t)y * W + x];
-            const float yv = target[((size_t)b * 3 + c) * HW + (size_t)y * W + x];
-            float g = sa[c] + sb[c] * xv + sc[c] * yv;
-            if (own) g += (0.15f / 3.f) * (xv > yv ? 1.f : (xv < yv ? -1.f : 0.f));
-            dpred[((size_t)n * 3 + c) * HW + (size_t)y * W + x] = g * wq;
-        }
+        for (int c = 0; c < 3; ++c) dpred[((size_t)n * 3 + c) * HW + (size_t)y * W + x] = g[c] * wq;
     }
+}
+
+// Fused loss backward for the whole pyramid (one launch): photometric gradient -> grid_sample / projection
+// / depth backward.  grid (nblk, B, nscale).  Writes ddisp_up[s,b,y,x] and dP_partial[s][b][blk][24].
+__global__ __launch_bounds__(256) void loss_bwd_kernel(Pyramid pyr, const unsigned char* __restrict__ sel_all,
+                                                       const float* __restrict__ coef_all, const float* __restrict__ warped_all,
+                                                       const float* __restrict__ target, const float* __restrict__ src_m1,
+                                                       const float* __restrict__ src_p1, const float* __restrict__ Kinv,
+                                                       const float* __restrict__ P, const float* __restrict__ sample_w,
+                                                       float* __restrict__ ddisp_up_all, float* __restrict__ dP_partial, int B,
+                                                       int H, int W, float da, float db, int dmode, int pix_per_block) {
+    __shared__ float red[4][24];
+    const int b = blockIdx.y, sc = blockIdx.z;
+    const int HW = H * W;
+    const int h = pyr.h[sc], w = pyr.w[sc];
+    const float* disp_s = pyr.disp[sc];
+    const unsigned char* sl = sel_all + ((size_t)sc * B + b) * HW;
+    const float* coef = coef_all + (size_t)sc * 2 * B * 9 * HW;
+    const float* warped = warped_all + (size_t)sc * 2 * B * 3 * HW;
+    float* ddisp_up = ddisp_up_all + (size_t)sc * B * HW;
+    const float wq = sample_w[b] / ((float)H * (float)W) / 4.f;
+    const int p0 = blockIdx.x * pix_per_block, p1 = min(HW, p0 + pix_per_block);
+    float dPacc[24];
+#pragma unroll
+    for (int k = 0; k < 24; ++k) dPacc[k] = 0.f;
+    const float* Ki = Kinv + (size_t)b * 16;
+    for (int pi = p0 + (int)threadIdx.x; pi < p1; pi += 256) {
+        const int x = pi % W, y = pi / W;
+        const float disp = upsample_disp(disp_s + (size_t)b * h * w, h, w, H, W, y, x);
+        const float dep = disp_to_depth_dev(disp, da, db, dmode);
+        const float fx = (float)x, fy = (float)y;
+        float cam[3], X[3];
+        for (int i = 0; i < 3; ++i) { cam[i] = Ki[i * 4 + 0] * fx + Ki[i * 4 + 1] * fy + Ki[i * 4 + 2]; X[i] = dep * cam[i]; }
+        float ddepth = 0.f;
+        for (int fi = 0; fi < 2; ++fi) {
+            const int n = fi * B + b;
+            float g3[3];
+            photo_grad_px(sl, coef + (size_t)n * 9 * HW, warped + (size_t)n * 3 * HW, target + (size_t)b * 3 * HW, H, W, y, x,
+                          (unsigned char)(2 + fi), g3);
+            const float* Pm = P + (size_t)n * 12;
+            float p[3];
+            for (int i = 0; i < 3; ++i) p[i] = Pm[i * 4 + 0] * X[0] + Pm[i * 4 + 1] * X[1] + Pm[i * 4 + 2] * X[2] + Pm[i * 4 + 3];
+            const float den = p[2] + 1e-7f;
+            const float u = p[0] / den, v = p[1] / den;
+            const Sample s = sample_coords(u, v, H, W);
+            const float wx1 = s.ix - (float)s.x0, wy1 = s.iy - (float)s.y0;
+            const float wx0 = (float)(s.x0 + 1) - s.ix, wy0 = (float)(s.y0 + 1) - s.iy;
+            const bool x1ok = s.x0 + 1 < W, y1ok = s.y0 + 1 < H;
+            const float* src = (fi == 0 ? src_m1 : src_p1) + (size_t)b * 3 * HW;
+            float gix = 0.f, giy = 0.f;
+            for (int c = 0; c < 3; ++c) {
+                const float g = g3[c] * wq;
+                const float* pl = src + (size_t)c * HW;
+                const float nw = pl[s.y0 * W + s.x0];
+                const float ne = x1ok ? pl[s.y0 * W + s.x0 + 1] : 0.f;
+                const float sw = y1ok ? pl[(s.y0 + 1) * W + s.x0] : 0.f;
+                const float se = (x1ok && y1ok) ? pl[(s.y0 + 1) * W + s.x0 + 1] : 0.f;
+                gix += g * (-nw * wy0 + ne * wy0 - sw * wy1 + se * wy1);
+                giy += g * (-nw * wx0 - ne * wx1 + sw * wx0 + se * wx1);
+            }
+            const float du = gix * s.mx, dv = giy * s.my;
+            float dp[3];
+            dp[0] = du / den;
+            dp[1] = dv / den;
+            dp[2] = -(du * u + dv * v) / den;
+            for (int i = 0; i < 3; ++i) {
+                dPacc[fi * 12 + i * 4 + 0] += dp[i] * X[0];
+                dPacc[fi * 12 + i * 4 + 1] += dp[i] * X[1];
+                dPacc[fi * 12 + i * 4 + 2] += dp[i] * X[2];
+                dPacc[fi * 12 + i * 4 + 3] += dp[i];
+            }
+            for (int j = 0; j < 3; ++j)
+                ddepth += (Pm[0 * 4 + j] * dp[0] + Pm[1 * 4 + j] * dp[1] + Pm[2 * 4 + j] * dp[2]) * cam[j];
+        }
+        ddisp_up[(size_t)b * HW + pi] = (dmode == 2) ? -db * dep * dep * ddepth : -dep / disp * ddepth;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 24; ++k) {
+        const float s = wave_sum(dPacc[k]);
+        if (lane == 0) red[wave][k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 24)
+        dP_partial[(((size_t)sc * B + b) * gridDim.x + blockIdx.x) * 24 + threadIdx.x] =
+            red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
 // ------------------------------------------------------------------------------------------------
 // dz[b,i,j] = sigmoid'(disp) * ( bilinear-upsample^T(ddisp_up)[b,i,j] + smoothness gradient )
-__global__ __launch_bounds__(256) void disp_grad_kernel(const float* __restrict__ ddisp_up, const float* __restrict__ disp,
-                                                        const float* __restrict__ smooth_aux, int n_smooth,
-                                                        float* __restrict__ dz, int B, int h, int w, int H, int W) {
+struct DzPtrs { float* dz[4]; };
+
+__global__ __launch_bounds__(256) void disp_grad_kernel(const float* ddisp_up, const float* disp, const float* smooth_aux,
+                                                        int n_smooth, float* dz, int B, int h, int w, int H, int W, Pyramid pyr,
+                                                        DzPtrs dzp) {
+    if (pyr.n > 0) {   // pyramid form: blockIdx.y = scale
+        const int sc = blockIdx.y;
+        h = pyr.h[sc]; w = pyr.w[sc];
+        disp = pyr.disp[sc];
+        dz = dzp.dz[sc];
+        ddisp_up += (size_t)sc * B * H * W;
+        if (smooth_aux) smooth_aux += (size_t)sc * (2 + 2 * n_smooth);
+    }
     const size_t total = (size_t)B * h * w;
     const int f = H / h;
     const float ry = (float)h / (float)H, rx = (float)w / (float)W;
@@ -350,13 +466,63 @@ extern "C" int clslam_automask(const float* idmap, const float* noise, const flo
     return check_launch("automask");
 }
 
+// nscale scales in one launch: noise (S,B,2,H,W) or NULL, rpmap (S,2,B,H,W), sel (S,B,H,W), partial (S,B,nblk)
+extern "C" int clslam_automask_pyramid(const float* idmap, const float* noise, const float* rpmap, unsigned char* sel,
+                                       float* partial, int nscale, int batch, int H, int W, void* stream) {
+    CLSLAM_REQUIRE(idmap && rpmap && sel && partial && nscale >= 1, "automask_pyramid: bad args");
+    if (!batch) return CLSLAM_OK;
+    const int nblk = clslam_automask_blocks(H, W);
+    hipLaunchKernelGGL(automask_kernel, dim3(nblk, batch, nscale), dim3(256), 0, (hipStream_t)stream, idmap, noise, rpmap, sel,
+                       partial, batch, H * W, cdiv(H * W, nblk));
+    return check_launch("automask_pyramid");
+}
+
 extern "C" int clslam_disp_mean_chunks(void) { return DM_CHUNKS; }
 
 extern "C" int clslam_disp_mean(const float* disp, float* means, int batch, int hw, void* stream) {
     CLSLAM_REQUIRE(disp && means, "disp_mean: null");
     if (!batch) return CLSLAM_OK;
-    hipLaunchKernelGGL(disp_mean_kernel, dim3(DM_CHUNKS, batch), dim3(256), 0, (hipStream_t)stream, disp, means, hw);
+    Pyramid pyr;
+    pyr.n = 1; pyr.disp[0] = disp; pyr.h[0] = 1; pyr.w[0] = hw;
+    for (int k = 1; k < 4; ++k) { pyr.disp[k] = nullptr; pyr.h[k] = pyr.w[k] = 0; }
+    hipLaunchKernelGGL(disp_mean_kernel, dim3(DM_CHUNKS, batch, 1), dim3(256), 0, (hipStream_t)stream, pyr, means, batch);
     return check_launch("disp_mean");
+}
+
+static Pyramid make_pyramid(const float* const* disp, int H, int W) {
+    Pyramid pyr;
+    pyr.n = 4;
+    for (int k = 0; k < 4; ++k) { pyr.disp[k] = disp[k]; pyr.h[k] = H >> k; pyr.w[k] = W >> k; }
+    return pyr;
+}
+
+// psum (4,B,chunks) for the four disparity maps disp[s] (B,H>>s,W>>s), one launch
+extern "C" int clslam_disp_mean_pyramid(const float* const* disp, float* psum, int batch, int H, int W, void* stream) {
+    CLSLAM_REQUIRE(disp && psum, "disp_mean_pyramid: null");
+    if (!batch) return CLSLAM_OK;
+    hipLaunchKernelGGL(disp_mean_kernel, dim3(DM_CHUNKS, batch, 4), dim3(256), 0, (hipStream_t)stream, make_pyramid(disp, H, W),
+                       psum, batch);
+    return check_launch("disp_mean_pyramid");
+}
+
+extern "C" int clslam_loss_bwd_blocks(int H, int W) { return std::max(1, std::min(256, cdiv(H * W, 1024))); }
+
+// Fused photometric + view-synthesis backward of all four scales (one launch).  sel (4,B,H,W),
+// coef (4,2,B,9,H,W), warped (4,2,B,3,H,W); ddisp_up (4,B,H,W); dp_partial [4][B][nblk][24].
+extern "C" int clslam_loss_bwd_pyramid(const float* const* disp, const unsigned char* sel, const float* coef, const float* warped,
+                                       const float* target, const float* src_m1, const float* src_p1, const float* inv_k,
+                                       const float* proj, const float* sample_w, float* ddisp_up, float* dp_partial, int batch,
+                                       int H, int W, float min_depth, float max_depth, void* stream) {
+    CLSLAM_REQUIRE(disp && sel && coef && warped && target && src_m1 && src_p1 && inv_k && proj && sample_w && ddisp_up &&
+                   dp_partial, "loss_bwd_pyramid: null");
+    float a, b; int mode;
+    depth_mode(min_depth, max_depth, &a, &b, &mode);
+    if (!batch) return CLSLAM_OK;
+    const int nblk = clslam_loss_bwd_blocks(H, W);
+    hipLaunchKernelGGL(loss_bwd_kernel, dim3(nblk, batch, 4), dim3(256), 0, (hipStream_t)stream, make_pyramid(disp, H, W), sel, coef,
+                       warped, target, src_m1, src_p1, inv_k, proj, sample_w, ddisp_up, dp_partial, batch, H, W, a, b, mode,
+                       cdiv(H * W, nblk));
+    return check_launch("loss_bwd_pyramid");
 }
 
 extern "C" int clslam_loss_finalize(const clslam_loss_desc* d, void* stream) {
@@ -388,7 +554,22 @@ extern "C" int clslam_disp_grad(const float* ddisp_up, const float* disp, const 
     CLSLAM_REQUIRE(n_smooth == 0 || (smooth_aux && n_smooth < w - 1 && h >= 2), "disp_grad: smoothness layout unsupported");
     const size_t total = (size_t)batch * h * w;
     if (!total) return CLSLAM_OK;
+    Pyramid none; none.n = 0;
+    for (int k = 0; k < 4; ++k) { none.disp[k] = nullptr; none.h[k] = none.w[k] = 0; }
+    DzPtrs dzp; for (int k = 0; k < 4; ++k) dzp.dz[k] = nullptr;
     hipLaunchKernelGGL(disp_grad_kernel, dim3(grid1d(total)), dim3(256), 0, (hipStream_t)stream, ddisp_up, disp, smooth_aux,
-                       n_smooth, dz, batch, h, w, H, W);
+                       n_smooth, dz, batch, h, w, H, W, none, dzp);
     return check_launch("disp_grad");
+}
+
+// all four scales in one launch: ddisp_up (4,B,H,W), smooth_aux [4][2+2*n_smooth], dz[s] (B,H>>s,W>>s)
+extern "C" int clslam_disp_grad_pyramid(const float* ddisp_up, const float* const* disp, const float* smooth_aux, int n_smooth,
+                                        float* const* dz, int batch, int H, int W, void* stream) {
+    CLSLAM_REQUIRE(ddisp_up && disp && dz, "disp_grad_pyramid: null");
+    CLSLAM_REQUIRE(n_smooth == 0 || (smooth_aux && n_smooth < (W >> 3) - 1 && (H >> 3) >= 2), "disp_grad_pyramid: smoothness layout unsupported");
+    if (!batch) return CLSLAM_OK;
+    DzPtrs dzp; for (int k = 0; k < 4; ++k) dzp.dz[k] = dz[k];
+    hipLaunchKernelGGL(disp_grad_kernel, dim3(grid1d((size_t)batch * H * W), 4), dim3(256), 0, (hipStream_t)stream, ddisp_up,
+                       (const float*)nullptr, smooth_aux, n_smooth, (float*)nullptr, batch, 0, 0, H, W, make_pyramid(disp, H, W), dzp);
+    return check_launch("disp_grad_pyramid");
 }

@@ -154,6 +154,11 @@ int clslam_pose_to_proj(const float* pose, const float* kmat, float* cam_t_cam, 
 int clslam_warp_fwd(const float* disp_s, int h, int w, const float* src_m1, const float* src_p1, const float* inv_k,
                     const float* proj, float* depth, float* warped, int batch, int H, int W, float min_depth,
                     float max_depth, void* stream);
+/* Pyramid forms (ONE launch for the four scales): disp = host array of 4 device pointers,
+ * disp[s] (B,H>>s,W>>s); depth (4,B,H,W); warped (4,2,B,3,H,W).                                     */
+int clslam_warp_fwd_pyramid(const float* const* disp, const float* src_m1, const float* src_p1, const float* inv_k,
+                            const float* proj, float* depth, float* warped, int batch, int H, int W, float min_depth,
+                            float max_depth, void* stream);
 int clslam_warp_bwd_blocks(int H, int W);
 /* ddisp_up (B,H,W) = dL/d(upsampled disparity); dp_partial [B][nblk][24] block sums of dL/dproj */
 int clslam_warp_bwd(const float* dpred, const float* disp_s, int h, int w, const float* src_m1, const float* src_p1,
@@ -180,6 +185,18 @@ int clslam_automask(const float* idmap, const float* noise, const float* rpmap, 
                     int batch, int H, int W, void* stream);
 /* psum [B][clslam_disp_mean_chunks()] partial sums of each sample's disparity map (the mean is
  * formed inside clslam_loss_finalize).                                                            */
+int clslam_automask_pyramid(const float* idmap, const float* noise, const float* rpmap, unsigned char* sel, float* partial,
+                            int nscale, int batch, int H, int W, void* stream);
+int clslam_disp_mean_pyramid(const float* const* disp, float* psum, int batch, int H, int W, void* stream);
+/* Fused clslam_photo_grad + clslam_warp_bwd for all four scales: sel (4,B,H,W), coef (4,2,B,9,H,W),
+ * warped (4,2,B,3,H,W) -> ddisp_up (4,B,H,W), dp_partial [4][B][clslam_loss_bwd_blocks][24].          */
+int clslam_loss_bwd_blocks(int H, int W);
+int clslam_loss_bwd_pyramid(const float* const* disp, const unsigned char* sel, const float* coef, const float* warped,
+                            const float* target, const float* src_m1, const float* src_p1, const float* inv_k,
+                            const float* proj, const float* sample_w, float* ddisp_up, float* dp_partial, int batch, int H,
+                            int W, float min_depth, float max_depth, void* stream);
+int clslam_disp_grad_pyramid(const float* ddisp_up, const float* const* disp, const float* smooth_aux, int n_smooth,
+                             float* const* dz, int batch, int H, int W, void* stream);
 int clslam_disp_mean_chunks(void);
 int clslam_disp_mean(const float* disp, float* psum, int batch, int hw, void* stream);
 typedef struct clslam_loss_desc {

@@ -9,7 +9,7 @@ from helpers import make_oracle, rel_err
 from oracle import functional as OF
 
 
-def _run_loss_stage(dev, inputs, disp, pose, noise, sample_w, smooth_w, H, W, min_depth, max_depth, train=True):
+def _run_loss_stage(dev, inputs, disp, pose, noise, sample_w, smooth_w, H, W, min_depth, max_depth, train=True, pyramid=False):
     """Sequence the loss-stage kernels exactly as the engine does (kept small and explicit here so
     the kernels are tested in isolation from the network)."""
     B = disp[0].shape[0]
@@ -23,8 +23,11 @@ def _run_loss_stage(dev, inputs, disp, pose, noise, sample_w, smooth_w, H, W, mi
     depth = torch.empty(4, B, H, W, device=dev)
     warped = torch.empty(4, 2, B, 3, H, W, device=dev)
     disp_d = [t(d) for d in disp]
-    for s in range(4):
-        ops.warp_fwd(disp_d[s], src[-1], src[1], Kinv, P, depth[s], warped[s], min_depth, max_depth)
+    if pyramid:
+        ops.warp_fwd_pyramid(disp_d, src[-1], src[1], Kinv, P, depth, warped, min_depth, max_depth)
+    else:
+        for s in range(4):
+            ops.warp_fwd(disp_d[s], src[-1], src[1], Kinv, P, depth[s], warped[s], min_depth, max_depth)
     idsrc = torch.stack([src[-1], src[1]]).contiguous()
     idmap = torch.empty(2, B, H, W, device=dev)
     ops.photo_map(idsrc, src[0], idmap, None, 2 * B, B, H, W)
@@ -34,10 +37,16 @@ def _run_loss_stage(dev, inputs, disp, pose, noise, sample_w, smooth_w, H, W, mi
     partial = torch.empty(4, B, nblk, device=dev)
     sel = torch.empty(4, B, H, W, dtype=torch.uint8, device=dev)
     means = torch.empty(4, B, ops.disp_mean_chunks(), device=dev)
-    for s in range(4):
-        ops.photo_map(warped[s], src[0], rpmap[s], coef[s] if train else None, 2 * B, B, H, W)
-        ops.automask(idmap, t(noise[s]) if noise is not None else None, rpmap[s], sel[s], partial[s], B, H, W)
-        ops.disp_mean(disp_d[s], means[s])
+    if pyramid:
+        noise_all = torch.stack([t(noise[s]) for s in range(4)]).contiguous() if noise is not None else None
+        ops.photo_map(warped, src[0], rpmap, coef if train else None, 8 * B, B, H, W)
+        ops.automask_pyramid(idmap, noise_all, rpmap, sel, partial, B, H, W)
+        ops.disp_mean_pyramid(disp_d, means, H, W)
+    else:
+        for s in range(4):
+            ops.photo_map(warped[s], src[0], rpmap[s], coef[s] if train else None, 2 * B, B, H, W)
+            ops.automask(idmap, t(noise[s]) if noise is not None else None, rpmap[s], sel[s], partial[s], B, H, W)
+            ops.disp_mean(disp_d[s], means[s])
     n_smooth = 0 if smooth_w is None else smooth_w.numel()
     losses = torch.empty(18, device=dev)
     aux = torch.zeros(4, 2 + 2 * max(n_smooth, 1), device=dev)[:, :2 + 2 * n_smooth].contiguous()
@@ -49,17 +58,26 @@ def _run_loss_stage(dev, inputs, disp, pose, noise, sample_w, smooth_w, H, W, mi
     out = dict(T=T, P=P, depth=depth, warped=warped, losses=losses, sel=sel)
     if not train:
         return out
-    nb2 = ops.warp_bwd_blocks(H, W)
-    dp_partial = torch.empty(4, B, nb2, 24, device=dev)
     dz = []
-    dpred = torch.empty(2, B, 3, H, W, device=dev)
-    ddisp_up = torch.empty(B, H, W, device=dev)
-    for s in range(4):
-        ops.photo_grad(sel[s], coef[s], warped[s], src[0], t(sample_w), dpred, B, H, W)
-        ops.warp_bwd(dpred, disp_d[s], src[-1], src[1], Kinv, P, ddisp_up, dp_partial[s], min_depth, max_depth)
-        g = torch.empty_like(disp_d[s])
-        ops.disp_grad(ddisp_up, disp_d[s], aux[s] if n_smooth else None, n_smooth, g, H, W)
-        dz.append(g)
+    if pyramid:
+        nb2 = ops.loss_bwd_blocks(H, W)
+        dp_partial = torch.empty(4, B, nb2, 24, device=dev)
+        ddisp_all = torch.empty(4, B, H, W, device=dev)
+        ops.loss_bwd_pyramid(disp_d, sel, coef, warped, src[0], src[-1], src[1], Kinv, P, t(sample_w), ddisp_all, dp_partial,
+                             min_depth, max_depth)
+        dz = [torch.empty_like(d) for d in disp_d]
+        ops.disp_grad_pyramid(ddisp_all, disp_d, aux if n_smooth else None, n_smooth, dz, H, W)
+    else:
+        nb2 = ops.warp_bwd_blocks(H, W)
+        dp_partial = torch.empty(4, B, nb2, 24, device=dev)
+        dpred = torch.empty(2, B, 3, H, W, device=dev)
+        ddisp_up = torch.empty(B, H, W, device=dev)
+        for s in range(4):
+            ops.photo_grad(sel[s], coef[s], warped[s], src[0], t(sample_w), dpred, B, H, W)
+            ops.warp_bwd(dpred, disp_d[s], src[-1], src[1], Kinv, P, ddisp_up, dp_partial[s], min_depth, max_depth)
+            g = torch.empty_like(disp_d[s])
+            ops.disp_grad(ddisp_up, disp_d[s], aux[s] if n_smooth else None, n_smooth, g, H, W)
+            dz.append(g)
     dpose = torch.empty(2 * B, 12, device=dev)
     ops.pose_bwd(dp_partial, 4, nb2, pose_d, K, d0, d1, t(sample_w), 0.05, dpose)
     out.update(dz=dz, dpose=dpose)
@@ -67,9 +85,10 @@ def _run_loss_stage(dev, inputs, disp, pose, noise, sample_w, smooth_w, H, W, mi
 
 
 @pytest.mark.parametrize('backend', BACKENDS)
+@pytest.mark.parametrize('pyramid', [False, True])
 @pytest.mark.parametrize('B,H,W,max_depth,aligned', [(2, 32, 64, None, False), (3, 64, 128, None, True),
                                                      (1, 32, 64, 80.0, True)])
-def test_loss_stage_matches_oracle(backend, B, H, W, max_depth, aligned):
+def test_loss_stage_matches_oracle(backend, B, H, W, max_depth, aligned, pyramid):
     dev = use_backend(backend)
     torch.manual_seed(3)
     inputs = synth.make_batch(B, H, W, seed=5)
@@ -111,7 +130,7 @@ def test_loss_stage_matches_oracle(backend, B, H, W, max_depth, aligned):
     losses['loss'].backward()
 
     got = _run_loss_stage(dev, inputs, [outputs['disp', s].squeeze(1) for s in range(4)], pose, noise, sw, sw, H, W, 0.1,
-                          max_depth)
+                          max_depth, pyramid=pyramid)
     for fi, f in enumerate((-1, 1)):
         assert rel_err(got['T'][fi].cpu(), Tm[f].detach()) < 1e-6
     for s in range(4):
