@@ -127,6 +127,7 @@ class Engine:
         # depth branch leaves idle at kernel tails
         self.side_stream = torch.cuda.Stream(device=device) if device.type == 'cuda' else None
         self.wg_stream = torch.cuda.Stream(device=device) if device.type == 'cuda' else None
+        self.depth_first = os.environ.get('CLSLAM_DEPTH_FIRST', '1') != '0'
         self.use_side_stream = os.environ.get('CLSLAM_SIDE_STREAM', '1') != '0'
 
     # ------------------------------------------------------------------------------------------
@@ -374,13 +375,24 @@ class Engine:
         if side is not None:
             main = torch.cuda.current_stream(self.device)
             side.wait_stream(main)
-            with torch.cuda.stream(side):
-                # pose pairs in temporal order (dpp.py:949-955): (-1, 0) and (0, +1), batched as 2B
-                pfeats = self._encoder(self.enc['pose_encoder'], ws.penc, 2 * B,
+
+            def pose_branch():
+                with torch.cuda.stream(side):
+                    # pose pairs in temporal order (dpp.py:949-955): (-1, 0) and (0, +1), batched as 2B
+                    pf = self._encoder(self.enc['pose_encoder'], ws.penc, 2 * B,
                                        [(aug[-1], aug[0], 0, B), (aug[0], aug[1], B, B)])
-                self._pose_decoder(ws, pfeats[4])
-            dfeats = self._encoder(self.enc['depth_encoder'], ws.denc, B, [(aug[0], None, 0, B)])
-            self._depth_decoder(ws, dfeats)
+                    self._pose_decoder(ws, pf[4])
+                    return pf
+            # the host enqueues ~50 launches per branch (~0.7 ms): the depth branch is the longer
+            # dependency chain (encoder + decoder), so its kernels go out first
+            if self.depth_first:
+                dfeats = self._encoder(self.enc['depth_encoder'], ws.denc, B, [(aug[0], None, 0, B)])
+                pfeats = pose_branch()
+                self._depth_decoder(ws, dfeats)
+            else:
+                pfeats = pose_branch()
+                dfeats = self._encoder(self.enc['depth_encoder'], ws.denc, B, [(aug[0], None, 0, B)])
+                self._depth_decoder(ws, dfeats)
             main.wait_stream(side)
         else:
             dfeats = self._encoder(self.enc['depth_encoder'], ws.denc, B, [(aug[0], None, 0, B)])

@@ -10,35 +10,41 @@ namespace clslam {
 
 // ------------------------------------------------------------------------------------------------
 // disp[b,y,x] = sigmoid(bias + sum_{tap,c} x[b, refl(y+ky-1), refl(x+kx-1), c] * w[tap][c])
+// C/4 lanes cooperate on one pixel (one float4 of channels each, 9 taps), then a butterfly over those
+// lanes; a wave covers 256/C pixels, loads are 16-byte and contiguous across the lanes of a pixel.
 __global__ __launch_bounds__(256) void dispconv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                            const float* __restrict__ bias, float* __restrict__ disp,
                                                            int B, int H, int W, int C) {
-    __shared__ __attribute__((aligned(16))) float ws[9 * 256];
-    for (int e = threadIdx.x; e < 9 * C; e += 256) ws[e] = w[e];
-    __syncthreads();
+    const int C4 = C / 4;                       // power of two in {4, 8, 16, 32}
+    const int ppb = 256 / C4;                   // pixels per block
+    const int cq = threadIdx.x % C4, pl = threadIdx.x / C4;
     const size_t total = (size_t)B * H * W;
     const float bv = bias[0];
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        const int xx = (int)(idx % W);
-        const int yy = (int)((idx / W) % H);
-        const int b = (int)(idx / ((size_t)W * H));
+    float4 wv[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wv[t] = *reinterpret_cast<const float4*>(w + t * C + cq * 4);
+    // every lane of the wave runs the same number of iterations (the shuffles need all lanes)
+    const size_t iters = (total + (size_t)gridDim.x * ppb - 1) / ((size_t)gridDim.x * ppb);
+    for (size_t itn = 0; itn < iters; ++itn) {
+        const size_t idx = (itn * gridDim.x + blockIdx.x) * ppb + pl;
+        const bool ok = idx < total;
+        const size_t id = ok ? idx : 0;
+        const int xx = (int)(id % W), yy = (int)((id / W) % H), b = (int)(id / ((size_t)W * H));
         float acc = 0.f;
+#pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
             const int iy = reflect_idx(yy + ky - 1, H);
+#pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
                 const int ix = reflect_idx(xx + kx - 1, W);
-                const float* px = x + (((size_t)b * H + iy) * W + ix) * C;
-                const float* pw = ws + (ky * 3 + kx) * C;
-                for (int c = 0; c < C; c += 4) {
-                    const float4 v = *reinterpret_cast<const float4*>(px + c);
-                    const float4 k = *reinterpret_cast<const float4*>(pw + c);
-                    acc = fmaf(v.x, k.x, acc); acc = fmaf(v.y, k.y, acc);
-                    acc = fmaf(v.z, k.z, acc); acc = fmaf(v.w, k.w, acc);
-                }
+                const float4 v = *reinterpret_cast<const float4*>(x + (((size_t)b * H + iy) * W + ix) * C + cq * 4);
+                const float4 k = wv[ky * 3 + kx];
+                acc = fmaf(v.x, k.x, acc); acc = fmaf(v.y, k.y, acc);
+                acc = fmaf(v.z, k.z, acc); acc = fmaf(v.w, k.w, acc);
             }
         }
-        acc += bv;
-        disp[idx] = 1.f / (1.f + expf(-acc));
+        for (int m = C4 >> 1; m >= 1; m >>= 1) acc += wave_shfl_xor(acc, m);
+        if (ok && cq == 0) disp[idx] = 1.f / (1.f + expf(-(acc + bv)));
     }
 }
 
@@ -188,10 +194,10 @@ static int grid_for(size_t total) { return (int)std::min<size_t>(4096, (total + 
 
 extern "C" int clslam_dispconv_fwd(const float* x, const float* w, const float* bias, float* disp, int batch, int h,
                                    int wd, int ch, void* stream) {
-    CLSLAM_REQUIRE(x && w && bias && disp && ch % 4 == 0 && ch <= 256, "dispconv_fwd: bad args");
+    CLSLAM_REQUIRE(x && w && bias && disp && (ch == 16 || ch == 32 || ch == 64 || ch == 128), "dispconv_fwd: ch must be 16/32/64/128");
     const size_t total = (size_t)batch * h * wd;
     if (!total) return CLSLAM_OK;
-    hipLaunchKernelGGL(dispconv_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, w, bias, disp,
+    hipLaunchKernelGGL(dispconv_fwd_kernel, dim3(grid_for(total * (ch / 4))), dim3(256), 0, (hipStream_t)stream, x, w, bias, disp,
                        batch, h, wd, ch);
     return check_launch("dispconv_fwd");
 }
@@ -206,7 +212,7 @@ extern "C" int clslam_dispconv_bwd_data(const float* dz, const float* w, float* 
     return check_launch("dispconv_bwd_data");
 }
 
-extern "C" int clslam_dispconv_wgrad_blocks(int pixels) { return std::max(1, std::min(512, cdiv(pixels, 512))); }
+extern "C" int clslam_dispconv_wgrad_blocks(int pixels) { return std::max(1, std::min(1024, cdiv(pixels, 128))); }
 
 // partial: clslam_dispconv_wgrad_blocks(B*h*w) * (9*ch+1) floats; reduce with clslam_reduce_partials
 // (n = 9*ch+1: the 9*ch weight gradients [tap][c] followed by the bias gradient).

@@ -32,4 +32,7 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// value of lane (lane ^ mask)
+__device__ __forceinline__ float wave_shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
+
 }  // namespace clslam

@@ -325,7 +325,8 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(Pyramid pyr, const unsign
         float cam[3], X[3];
         for (int i = 0; i < 3; ++i) { cam[i] = Ki[i * 4 + 0] * fx + Ki[i * 4 + 1] * fy + Ki[i * 4 + 2]; X[i] = dep * cam[i]; }
         float ddepth = 0.f;
-        for (int fi = 0; fi < 2; ++fi) {
+#pragma unroll 1
+        for (int fi = 0; fi < 2; ++fi) {   // not unrolled: halves the live registers (occupancy 2 -> 4 waves/SIMD)
             const int n = fi * B + b;
             float g3[3];
             photo_grad_px(sl, coef + (size_t)n * 9 * HW, warped + (size_t)n * 3 * HW, target + (size_t)b * 3 * HW, H, W, y, x,
@@ -356,11 +357,19 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(Pyramid pyr, const unsign
             dp[0] = du / den;
             dp[1] = dv / den;
             dp[2] = -(du * u + dv * v) / den;
-            for (int i = 0; i < 3; ++i) {
-                dPacc[fi * 12 + i * 4 + 0] += dp[i] * X[0];
-                dPacc[fi * 12 + i * 4 + 1] += dp[i] * X[1];
-                dPacc[fi * 12 + i * 4 + 2] += dp[i] * X[2];
-                dPacc[fi * 12 + i * 4 + 3] += dp[i];
+            // dPacc is indexed with compile-time constants only (a runtime index would spill it to scratch)
+            if (fi == 0) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    dPacc[i * 4 + 0] += dp[i] * X[0]; dPacc[i * 4 + 1] += dp[i] * X[1];
+                    dPacc[i * 4 + 2] += dp[i] * X[2]; dPacc[i * 4 + 3] += dp[i];
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    dPacc[12 + i * 4 + 0] += dp[i] * X[0]; dPacc[12 + i * 4 + 1] += dp[i] * X[1];
+                    dPacc[12 + i * 4 + 2] += dp[i] * X[2]; dPacc[12 + i * 4 + 3] += dp[i];
+                }
             }
             for (int j = 0; j < 3; ++j)
                 ddepth += (Pm[0 * 4 + j] * dp[0] + Pm[1 * 4 + j] * dp[1] + Pm[2 * 4 + j] * dp[2]) * cam[j];

@@ -58,4 +58,12 @@ inline float wave_sum(float v) {
     return v;
 }
 
+inline float wave_shfl_xor(float v, int mask) {
+    const int l = lane_id();
+    float* s = emu_wave_scratch() + emu_wave_phase() * 128;
+    s[l] = v;
+    emu_sync_wave();
+    return s[l ^ mask];
+}
+
 }  // namespace clslam
