@@ -163,12 +163,13 @@ def main():
                  2: 'conv_igemm_kernel<32, 32, 32, 16, 2>', 3: 'conv_igemm_kernel<64, 32, 32, 16, 2>',
                  4: 'conv_igemm_kernel<128, 16, 16, 16, 4>', 5: 'conv_igemm_kernel<64, 32, 16, 16, 2>',
                  6: 'conv_igemm_kernel<128, 16, 32, 16, 4>', 10: 'conv3x3_patch_kernel<8, 16, 64, 16, 32, 2>',
-                 11: 'conv3x3_patch_kernel<8, 16, 32, 16, 32, 4>', 12: 'conv3x3_patch_kernel<8, 16, 16, 16, 16, 4, false, 4>',
+                 11: 'conv3x3_patch_kernel<8, 16, 32, 16, 32, 4>', 12: 'conv3x3_patch_kernel<8, 16, 16, 16, 16, 4, false, 4, 1>',
                  13: 'conv3x3_patch_kernel<4, 16, 64, 16, 32, 2>', 14: 'conv3x3_patch_kernel<8, 16, 16, 32, 16, 4>',
                  15: 'conv3x3_patch_kernel<16, 16, 16, 16, 16, 4>', 16: 'conv3x3_patch_kernel<8, 16, 32, 16, 16, 4>',
-                 17: 'conv3x3_patch_kernel<4, 16, 16, 16, 16, 4, false, 4>', 18: 'conv3x3_patch_kernel<4, 16, 16, 16, 16, 4, true, 4>',
-                 19: 'conv3x3_patch_kernel<8, 16, 16, 16, 16, 4, true, 4>', 20: 'conv3x3_patch_kernel<8, 16, 16, 16, 16, 4, false, 8>',
-                 21: 'conv3x3_patch_kernel<4, 16, 16, 16, 16, 4, false, 8>', 22: 'conv3x3_patch_kernel<4, 16, 16, 16, 16, 4, true, 8>'}
+                 17: 'conv3x3_patch_kernel<4, 16, 16, 16, 16, 4, false, 4, 1>', 18: 'conv3x3_patch_kernel<4, 16, 16, 16, 16, 4, true, 4, 1>',
+                 19: 'conv3x3_patch_kernel<8, 16, 16, 16, 16, 4, true, 4, 1>', 20: 'conv3x3_patch_kernel<8, 16, 16, 16, 16, 4, false, 8, 1>',
+                 21: 'conv3x3_patch_kernel<4, 16, 16, 16, 16, 4, false, 8, 1>', 22: 'conv3x3_patch_kernel<4, 16, 16, 16, 16, 4, true, 8, 1>',
+                 23: 'conv3x3_patch_kernel<4, 16, 16, 16, 16, 4, false, 8, 2>'}
         (kind, cfg), (fl, tt, cnt) = max(agg.items(), key=lambda kv: kv[1][1])
         all_fl = sum(a[0] for a in agg.values())
         all_t = sum(a[1] for a in agg.values())

@@ -248,6 +248,8 @@ extern "C" int clslam_conv2d_pick_config(const clslam_conv_desc* d) {
     // (a 4x16 rectangle wastes half its lanes there); all beat every conv_igemm tiling (26-67).
     if (d->ksize == 3 && d->stride == 1 && d->out_h == d->in_h + 2 * d->pad - 2 && d->out_w == d->in_w + 2 * d->pad - 2)
         return d->out_w <= 24 ? 22 : (M >= 30000 ? 12 : 21);   // narrow images: run tiles
+    if (d->ksize == 3 && d->stride == 2 && d->out_h == (d->in_h + 2 * d->pad - 3) / 2 + 1 && d->out_w == (d->in_w + 2 * d->pad - 3) / 2 + 1)
+        return 23;
     if (d->ch_out % 32 != 0) return bk32 ? 6 : 4;
     if (!bk32) return 5;
     if (d->ch_out == 32) return 3;

@@ -37,10 +37,11 @@ struct PatchK {
 // the patch is the full-width band of input rows it touches (runtime PH x (Wo+2), bounded by run_pp(BM)).
 constexpr int run_pp(int bm) { return bm <= 64 ? 224 : 320; }
 
-template <int TH, int TW, int BN, int BK, int MF, int WGM, bool RUN, int LDPAD>
+template <int TH, int TW, int BN, int BK, int MF, int WGM, bool RUN, int LDPAD, int S>
 __global__ __launch_bounds__(256) void conv3x3_patch_kernel(PatchK p) {
     constexpr int BM = TH * TW;
-    constexpr int PH = TH + 2, PW = TW + 2, PP = RUN ? run_pp(BM) : PH * PW;
+    constexpr int PH = (TH - 1) * S + 3, PW = (TW - 1) * S + 3, PP = RUN ? run_pp(BM) : PH * PW;   // S = conv stride
+    static_assert(!RUN || S == 1, "run tiles are stride-1 only");
     constexpr int LD = BK + LDPAD;   // +4: rows 16-B aligned; +8 with BK=16 makes the 16x16x4 fragment reads conflict-free
     constexpr int WGN = 4 / WGM;
     constexpr int WM = BM / WGM, WN = BN / WGN;
@@ -82,7 +83,7 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(PatchK p) {
         offA[it] = -1; offB[it] = -1;
         if (f < P_SLOTS && pp < npatch) {
             const int pr = pp / pw, pc = pp - pr * pw;
-            int iy = oy0 - p.pad + pr, ix = ox0 - p.pad + pc;
+            int iy = oy0 * S - p.pad + pr, ix = ox0 * S - p.pad + pc;
             bool ok = true;
             if (p.pad_mode == CLSLAM_PAD_REFLECT) {
                 iy = reflect_idx(iy, p.Hi); ix = reflect_idx(ix, p.Wi);
@@ -157,7 +158,7 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(PatchK p) {
             const int mm = min(m0 + m, p.Ho * p.Wo - 1);
             prow[i] = (mm / p.Wo - oy0) * pw + (mm % p.Wo);
         } else {
-            prow[i] = (m / TW) * PW + (m % TW);
+            prow[i] = (m / TW) * S * PW + (m % TW) * S;
         }
     }
 
@@ -230,7 +231,7 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(PatchK p) {
     }
 }
 
-template <int TH, int TW, int BN, int BK, int MF, int WGM, bool RUN = false, int LDPAD = 4>
+template <int TH, int TW, int BN, int BK, int MF, int WGM, bool RUN = false, int LDPAD = 4, int S = 1>
 static int launch_patch(PatchK k, hipStream_t stream) {
     if (RUN) {
         const int spanned = (TH * TW - 1 + k.Wo - 1) / k.Wo + 1;
@@ -240,14 +241,18 @@ static int launch_patch(PatchK k, hipStream_t stream) {
     k.tilesY = RUN ? 1 : cdiv(k.Ho, TH);
     k.tilesN = cdiv(k.Cout, BN);
     k.nblk = k.tilesX * k.tilesY * k.tilesN * k.B;
-    hipLaunchKernelGGL((conv3x3_patch_kernel<TH, TW, BN, BK, MF, WGM, RUN, LDPAD>), dim3(k.nblk), dim3(256), 0, stream, k);
+    hipLaunchKernelGGL((conv3x3_patch_kernel<TH, TW, BN, BK, MF, WGM, RUN, LDPAD, S>), dim3(k.nblk), dim3(256), 0, stream, k);
     return check_launch("conv3x3_patch");
 }
 
 // Called by clslam_conv2d for configs >= 10.
 int conv3x3_patch_dispatch(const clslam_conv_desc* d, int cfg, hipStream_t stream) {
-    if (d->ksize != 3 || d->stride != 1) { set_error("conv2d: patch configs need a 3x3 stride-1 conv"); return CLSLAM_ERR_INVALID; }
-    if (d->out_h != d->in_h + 2 * d->pad - 2 || d->out_w != d->in_w + 2 * d->pad - 2) {
+    const int st = d->stride;
+    if (d->ksize != 3 || (st != 1 && st != 2) || (st == 2) != (cfg == 23)) {
+        set_error("conv2d: patch configs need a 3x3 conv with stride 1 (configs 10-22) or 2 (config 23)");
+        return CLSLAM_ERR_INVALID;
+    }
+    if (d->out_h != (d->in_h + 2 * d->pad - 3) / st + 1 || d->out_w != (d->in_w + 2 * d->pad - 3) / st + 1) {
         set_error("conv2d: inconsistent output size for the patch kernel");
         return CLSLAM_ERR_INVALID;
     }
@@ -271,6 +276,7 @@ int conv3x3_patch_dispatch(const clslam_conv_desc* d, int cfg, hipStream_t strea
         case 20: return launch_patch<8, 16, 16, 16, 16, 4, false, 8>(k, stream);  // = 12 with conflict-free rows
         case 21: return launch_patch<4, 16, 16, 16, 16, 4, false, 8>(k, stream);  // = 17 with conflict-free rows
         case 22: return launch_patch<4, 16, 16, 16, 16, 4, true, 8>(k, stream);   // = 18 with conflict-free rows
+        case 23: return launch_patch<4, 16, 16, 16, 16, 4, false, 8, 2>(k, stream);  // stride-2 convs (encoder stage entries)
         default: set_error("conv2d: unknown patch config %d", cfg); return CLSLAM_ERR_INVALID;
     }
 }

@@ -6,23 +6,30 @@
 //            torch.cat of dpp.py:951-955 never materialises) and writing NHWC.
 //   maxpool: 3x3 s2 p1 (:121).
 // The stem is an implicit GEMM on v_mfma_f32_32x32x2_f32: M = 8x16 output pixels per block,
-// N = 64 output channels, K = 49 taps (+1 zero) per input channel; per channel the 21x37 input
-// patch (normalised, zero outside the image = zero padding of the normalised tensor) and the
-// 64x49 weight slice are staged in LDS.
+// N = 64 output channels, K = 3*49 (+1 zero) per pass of three input channels; per pass the 3x21x37
+// input patch (normalised, zero outside the image = zero padding of the normalised tensor) and the
+// 64x147 weight slab are staged in LDS (47 KB -> 3 blocks per CU).
 #include "common.h"
 
 namespace clslam {
 
 constexpr int ST_TH = 8, ST_TW = 16;                  // output tile
-constexpr int ST_PH = 2 * ST_TH + 5, ST_PW = 2 * ST_TW + 5;  // 21 x 37 input patch
-constexpr int ST_LDW = 51;                            // weight row stride (odd -> conflict-free column reads)
+constexpr int ST_PH = 2 * ST_TH + 5, ST_PW = 2 * ST_TW + 5;  // 21 x 37 input patch per channel
+constexpr int ST_CG = 3;                              // input channels staged per pass
+constexpr int ST_K = ST_CG * 49;                      // 147 reduction elements per pass (+1 zero)
+constexpr int ST_LDW = 149;                           // weight row stride (odd -> conflict-free column reads)
+
+// LDS patch offset of reduction element k = (c, ky, kx) of a pass
+__device__ __forceinline__ constexpr int st_koff(int k) {
+    return (k / 49) * (ST_PH * ST_PW) + ((k % 49) / 7) * ST_PW + (k % 7);
+}
 
 __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict__ img_a, const float* __restrict__ img_b,
                                                         const float* __restrict__ w, const float* __restrict__ scale,
                                                         const float* __restrict__ shift, float* __restrict__ out,
                                                         int B, int H, int W, int Cin, int Ho, int Wo, int tiles_x,
                                                         int tiles_y) {
-    __shared__ float patch[ST_PH * ST_PW];
+    __shared__ float patch[ST_CG * ST_PH * ST_PW];
     __shared__ float Ws[64 * ST_LDW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int bid = blockIdx.x;
@@ -42,29 +49,34 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
     const int py = wave * 2 + (i >> 4), px = i & 15;      // this lane's output pixel inside the tile
     const int pbase = (2 * py) * ST_PW + 2 * px;
 
-    for (int c = 0; c < Cin; ++c) {
-        const float* img = (c < 3) ? img_a + ((size_t)b * 3 + c) * H * W : img_b + ((size_t)b * 3 + (c - 3)) * H * W;
+    // one pass per group of 3 input channels (depth net: 1 pass, pose net: 2): stage the 3 x 21 x 37
+    // normalised patch and the 64 x 147 weight slab, then 74 MFMA k-steps without further barriers
+    for (int c0 = 0; c0 < Cin; c0 += ST_CG) {
         __syncthreads();
-        for (int e = tid; e < ST_PH * ST_PW; e += 256) {
-            const int r = e / ST_PW, q = e - r * ST_PW;
+        for (int e = tid; e < ST_CG * ST_PH * ST_PW; e += 256) {
+            const int c = e / (ST_PH * ST_PW), rem = e - c * (ST_PH * ST_PW);
+            const int r = rem / ST_PW, q = rem - r * ST_PW;
             const int iy = iy0 + r, ix = ix0 + q;
-            float v = 0.f;
-            if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = (img[(size_t)iy * W + ix] - 0.45f) / 0.225f;
-            patch[e] = v;
+            const int cc = c0 + c;
+            const float* img = (cc < 3) ? img_a + ((size_t)b * 3 + cc) * H * W : img_b + ((size_t)b * 3 + (cc - 3)) * H * W;
+            const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+            const float raw = img[ok ? (size_t)iy * W + ix : 0];
+            patch[e] = ok ? (raw - 0.45f) / 0.225f : 0.f;
         }
-        for (int e = tid; e < 64 * 50; e += 256) {
-            const int co = e / 50, k = e - co * 50;
-            Ws[co * ST_LDW + k] = (k < 49) ? w[((size_t)co * Cin + c) * 49 + k] : 0.f;
+        for (int e = tid; e < 64 * (ST_K + 1); e += 256) {
+            const int co = e / (ST_K + 1), k = e - co * (ST_K + 1);
+            Ws[co * ST_LDW + k] = (k < ST_K) ? w[((size_t)co * Cin + c0) * 49 + k] : 0.f;
         }
         __syncthreads();
-#pragma unroll 5
-        for (int s = 0; s < 25; ++s) {
-            const int k = 2 * s + g;
-            const int kk = k < 49 ? k : 0;                 // k = 49 is the zero pad column
-            const int ky = kk / 7, kx = kk - ky * 7;
-            const float a = patch[pbase + ky * ST_PW + kx];
-            const float b0 = Ws[i * ST_LDW + k];
-            const float b1 = Ws[(32 + i) * ST_LDW + k];
+#pragma unroll
+        for (int s = 0; s < (ST_K + 1) / 2; ++s) {
+            // k = 2s + g; k = 147 is the zero pad column (any in-range patch element will do)
+            constexpr int dummy = 0;
+            const int off0 = st_koff(2 * s);
+            const int off1 = (2 * s + 1 < ST_K) ? st_koff(2 * s + 1) : dummy;
+            const float a = patch[pbase + (g ? off1 : off0)];
+            const float b0 = Ws[i * ST_LDW + 2 * s + g];
+            const float b1 = Ws[(32 + i) * ST_LDW + 2 * s + g];
             acc[0] = mfma_32x32x2(a, b0, acc[0]);
             acc[1] = mfma_32x32x2(a, b1, acc[1]);
         }

@@ -184,7 +184,7 @@ using namespace clslam;
 
 extern "C" int clslam_wgrad_patch_supported(const clslam_conv_desc* d) {
     return d->ksize == 3 && d->stride == 1 && d->out_h == d->in_h + 2 * d->pad - 2 && d->out_w == d->in_w + 2 * d->pad - 2 &&
-           d->out_w > 24 && d->ch_out % 16 == 0 && (d->ch_a + d->ch_b) % 16 == 0 && d->ch_a % 16 == 0;
+           d->out_w > 40 && d->ch_out % 16 == 0 && (d->ch_a + d->ch_b) % 16 == 0 && d->ch_a % 16 == 0;
 }
 
 extern "C" int clslam_wgrad_patch_splits(const clslam_conv_desc* d, int target_blocks) {

@@ -97,7 +97,7 @@ int clslam_fold_act_grad(const float* dxp, const float* yout, float* dz, float* 
 /* Weight gradient as an MFMA GEMM reducing over pixels; desc = the forward conv's descriptor. */
 int clslam_wgrad_splits(const clslam_conv_desc* desc, int target_blocks);
 int clslam_conv_wgrad(const clslam_conv_desc* desc, const float* dz, float* partial, int splits, void* stream);
-/* Same contract as clslam_conv_wgrad for 3x3 stride-1 convs on images wider than 24 px, with the dZ
+/* Same contract as clslam_conv_wgrad for 3x3 stride-1 convs on images wider than 40 px, with the dZ
  * tile and the input patch resident in LDS (wgrad_patch.hip); splits from clslam_wgrad_patch_splits. */
 int clslam_wgrad_patch_supported(const clslam_conv_desc* desc);
 int clslam_wgrad_patch_splits(const clslam_conv_desc* desc, int target_blocks);

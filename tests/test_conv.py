@@ -62,6 +62,8 @@ CASES = [
     (1, 10, 36, 32, 0, 32, 3, 1, 1, False, 2, False, 20),
     (2, 6, 20, 32, 0, 48, 3, 1, 0, False, 1, False, 21),
     (2, 6, 20, 32, 0, 48, 3, 1, 0, False, 1, False, 22),
+    (2, 12, 40, 32, 0, 64, 3, 2, 0, False, 1, False, 23),
+    (1, 9, 21, 16, 0, 32, 3, 2, 0, False, 1, False, 23),
 ]
 
 
