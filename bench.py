@@ -146,6 +146,11 @@ def main():
     # ---- roofline of the dominant kernel (instrumented extra step, outside the timed region) ------
     roof = None
     if rank == 0:
+        # serial launch order for this pass: with the pose / wgrad side streams active several kernels share
+        # the GPU and a launch's own duration is not its kernel's efficiency
+        p.engine.use_side_stream = False
+        step()
+        torch.cuda.synchronize()
         ops.PROFILE = []
         step()
         torch.cuda.synchronize()

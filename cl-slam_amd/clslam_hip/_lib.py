@@ -56,6 +56,8 @@ _SIGNATURES = {
     'clslam_reduce_multi': [fptr, i32, i32, C.c_void_p],
     'clslam_colsum_blocks': [i32],
     'clslam_colsum': [fptr, fptr, i32, i32, C.c_void_p],
+    'clslam_stem_packed_size': [i32],
+    'clslam_stem_pack_weight': [fptr, fptr, i32, C.c_void_p],
     'clslam_stem_conv': [fptr, fptr, fptr, fptr, fptr, fptr, i32, i32, i32, i32, C.c_void_p],
     'clslam_maxpool3x3s2': [fptr, fptr, i32, i32, i32, i32, C.c_void_p],
     'clslam_dispconv_fwd': [fptr, fptr, fptr, fptr, i32, i32, i32, i32, C.c_void_p],

@@ -170,7 +170,7 @@ class Engine:
                 wt = sd[key]
                 return wt.permute(0, 2, 3, 1).reshape(wt.shape[0], wt.shape[2] * wt.shape[3], wt.shape[1]).contiguous()
 
-            e.stem_w = sd['resnet.conv1.weight'].contiguous()
+            e.stem_w = ops.stem_pack_weight(sd['resnet.conv1.weight'].contiguous())
             e.stem_scale, e.stem_shift = bn('resnet.bn1')
             e.blocks = []
             for li, (cin, cout, stride) in enumerate(((64, 64, 1), (64, 128, 2), (128, 256, 2), (256, 512, 2)), start=1):

@@ -147,8 +147,16 @@ def colsum(x, partial, rows, ch):
     return partial
 
 
+def stem_pack_weight(weight):
+    """OIHW (64,3|6,7,7) conv1 weight -> packed LDS-image slabs for stem_conv"""
+    n_img = weight.shape[1] // 3
+    packed = torch.empty(_lib.get_lib().cdll.clslam_stem_packed_size(n_img), device=weight.device)
+    _lib.get_lib().call('clslam_stem_pack_weight', _p(weight), _p(packed), n_img, _stream(weight))
+    return packed
+
+
 def stem_conv(img_a, img_b, weight, scale, shift, out):
-    """img_* planar (B,3,H,W); weight OIHW (64,3|6,7,7); out NHWC (B,H/2,W/2,64)."""
+    """img_* planar (B,3,H,W); weight = stem_pack_weight(conv1.weight); out NHWC (B,H/2,W/2,64)."""
     B, _, H, W = img_a.shape
     n_img = 1 if img_b is None else 2
     _lib.get_lib().call('clslam_stem_conv', _p(img_a), _p(img_b), _p(weight), _p(scale), _p(shift), _p(out),

@@ -280,17 +280,40 @@ struct ReduceItem { const float* partial; float* out; unsigned long long n; int 
 
 __global__ __launch_bounds__(256) void reduce_multi_kernel(const ReduceItem* __restrict__ items) {
     constexpr int IL = 64, KL = 4;
-    __shared__ float red[256];
+    __shared__ float4 red[256];
     const ReduceItem it = items[blockIdx.y];
     const int il = threadIdx.x % IL, kl = threadIdx.x / IL;
+    if ((it.n & 3) == 0) {   // 16-byte path (all conv weights / biases)
+        const size_t n4 = it.n >> 2;
+        for (size_t i0 = (size_t)blockIdx.x * IL; i0 < n4; i0 += (size_t)gridDim.x * IL) {
+            const size_t i = i0 + il;
+            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < n4)
+                for (int k = kl; k < it.splits; k += KL) {
+                    const float4 v = reinterpret_cast<const float4*>(it.partial + (size_t)k * it.n)[i];
+                    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+                }
+            red[threadIdx.x] = s;
+            __syncthreads();
+            if (kl == 0 && i < n4) {
+                float4 t = red[il];
+#pragma unroll
+                for (int q = 1; q < KL; ++q) { const float4 v = red[q * IL + il]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+                t.x *= it.scale; t.y *= it.scale; t.z *= it.scale; t.w *= it.scale;
+                reinterpret_cast<float4*>(it.out)[i] = t;
+            }
+            __syncthreads();
+        }
+        return;
+    }
     for (size_t i0 = (size_t)blockIdx.x * IL; i0 < it.n; i0 += (size_t)gridDim.x * IL) {
         const size_t i = i0 + il;
         float s = 0.f;
         if (i < it.n)
             for (int k = kl; k < it.splits; k += KL) s += it.partial[(size_t)k * it.n + i];
-        red[threadIdx.x] = s;
+        red[threadIdx.x].x = s;
         __syncthreads();
-        if (kl == 0 && i < it.n) it.out[i] = (red[il] + red[IL + il] + red[2 * IL + il] + red[3 * IL + il]) * it.scale;
+        if (kl == 0 && i < it.n) it.out[i] = (red[il].x + red[IL + il].x + red[2 * IL + il].x + red[3 * IL + il].x) * it.scale;
         __syncthreads();
     }
 }

@@ -5,6 +5,7 @@
 //            sample dict directly (for the pose net the two frames are two pointers, the
 //            torch.cat of dpp.py:951-955 never materialises) and writing NHWC.
 //   maxpool: 3x3 s2 p1 (:121).
+// (The conv weight arrives pre-packed: clslam_stem_pack_weight, once per load.)
 // The stem is an implicit GEMM on v_mfma_f32_32x32x2_f32: M = 8x16 output pixels per block,
 // N = 64 output channels, K = 3*49 (+1 zero) per pass of three input channels; per pass the 3x21x37
 // input patch (normalised, zero outside the image = zero padding of the normalised tensor) and the
@@ -63,10 +64,9 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
             const float raw = img[ok ? (size_t)iy * W + ix : 0];
             patch[e] = ok ? (raw - 0.45f) / 0.225f : 0.f;
         }
-        for (int e = tid; e < 64 * (ST_K + 1); e += 256) {
-            const int co = e / (ST_K + 1), k = e - co * (ST_K + 1);
-            Ws[co * ST_LDW + k] = (k < ST_K) ? w[((size_t)co * Cin + c0) * 49 + k] : 0.f;
-        }
+        // weight slab of this pass, pre-packed by the host in the LDS image [64][ST_LDW] (zero padded)
+        const float* wp = w + (size_t)(c0 / ST_CG) * 64 * ST_LDW;
+        for (int e = tid; e < 64 * ST_LDW; e += 256) Ws[e] = wp[e];
         __syncthreads();
 #pragma unroll
         for (int s = 0; s < (ST_K + 1) / 2; ++s) {
@@ -124,6 +124,24 @@ __global__ void maxpool3x3s2_kernel(const float* __restrict__ in, float* __restr
 }  // namespace clslam
 
 using namespace clslam;
+
+__global__ void stem_pack_kernel(const float* __restrict__ w, float* __restrict__ packed, int Cin) {
+    // packed[pass][co][k] = w[co][pass*3 + k/49][k%49]  (k < 147), 0 for the pad columns
+    const int total = (Cin / ST_CG) * 64 * ST_LDW;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const int k = e % ST_LDW, co = (e / ST_LDW) % 64, ps = e / (ST_LDW * 64);
+        packed[e] = (k < ST_K) ? w[((size_t)co * Cin + ps * ST_CG) * 49 + k] : 0.f;
+    }
+}
+
+extern "C" int clslam_stem_packed_size(int num_images) { return num_images * 64 * ST_LDW; }
+
+// weight: OIHW (64, 3*num_images, 7, 7) as in the checkpoint -> packed slabs for clslam_stem_conv
+extern "C" int clslam_stem_pack_weight(const float* weight, float* packed, int num_images, void* stream) {
+    CLSLAM_REQUIRE(weight && packed && (num_images == 1 || num_images == 2), "stem_pack_weight: bad args");
+    hipLaunchKernelGGL(stem_pack_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, weight, packed, 3 * num_images);
+    return check_launch("stem_pack_weight");
+}
 
 extern "C" int clslam_stem_conv(const float* img_a, const float* img_b, const float* weight, const float* scale,
                                 const float* shift, float* out, int batch, int h, int w, int num_images, void* stream) {

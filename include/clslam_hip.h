@@ -115,7 +115,10 @@ int clslam_colsum(const float* x, float* partial, int rows, int ch, void* stream
  * Encoder stem (frozen): (x-0.45)/0.225 -> conv7x7 s2 p3 -> eval BN -> ReLU, and maxpool 3x3 s2 p1.
  * Replaces networks/resnet_encoder.py:117-121.  img_a/img_b: planar (B,3,h,w) frames exactly as
  * the sample dict holds them (img_b = second frame of the pose pair, dpp.py:951-955, or NULL);
- * weight: (64, 3*num_images, 7, 7) in the checkpoint's OIHW order; out: NHWC (B,h/2,w/2,64).     */
+ * weight: the conv1 weight (64, 3*num_images, 7, 7), checkpoint OIHW order, re-packed ONCE per load by
+ * clslam_stem_pack_weight into clslam_stem_packed_size(num_images) floats; out: NHWC (B,h/2,w/2,64). */
+int clslam_stem_packed_size(int num_images);
+int clslam_stem_pack_weight(const float* weight, float* packed, int num_images, void* stream);
 int clslam_stem_conv(const float* img_a, const float* img_b, const float* weight, const float* scale,
                      const float* shift, float* out, int batch, int h, int w, int num_images, void* stream);
 int clslam_maxpool3x3s2(const float* in, float* out, int batch, int h, int w, int ch, void* stream);

@@ -21,7 +21,8 @@ def test_stem_and_maxpool(backend, n_img, B, H, W):
     ref = F.relu(F.conv2d(x, w, stride=2, padding=3) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
     Ho, Wo = ref.shape[2:]
     out = torch.full((B, Ho, Wo, 64), float('nan'), device=dev)
-    ops.stem_conv(imgs[0].to(dev), imgs[1].to(dev) if n_img == 2 else None, w.to(dev), scale.to(dev), shift.to(dev), out)
+    ops.stem_conv(imgs[0].to(dev), imgs[1].to(dev) if n_img == 2 else None, ops.stem_pack_weight(w.to(dev)), scale.to(dev),
+                  shift.to(dev), out)
     assert rel_err(out.cpu().permute(0, 3, 1, 2), ref) < 2e-5
     refp = F.max_pool2d(ref, 3, 2, 1)
     outp = torch.full((B, refp.shape[2], refp.shape[3], 64), float('nan'), device=dev)
