@@ -279,9 +279,12 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
 struct ReduceItem { const float* partial; float* out; unsigned long long n; int splits; float scale; };
 
 __global__ __launch_bounds__(256) void reduce_multi_kernel(const ReduceItem* __restrict__ items) {
-    constexpr int IL = 64, KL = 4;
     __shared__ float4 red[256];
     const ReduceItem it = items[blockIdx.y];
+    // few outputs + many splits (bias gradients: n = 16..256, hundreds of per-block partials): spend the
+    // block's lanes on the split axis instead (16 output lanes x 16 split lanes)
+    const int IL = ((it.n >> 2) <= 16 && (it.n & 3) == 0) ? 16 : 64;
+    const int KL = 256 / IL;
     const int il = threadIdx.x % IL, kl = threadIdx.x / IL;
     if ((it.n & 3) == 0) {   // 16-byte path (all conv weights / biases)
         const size_t n4 = it.n >> 2;
@@ -297,7 +300,6 @@ __global__ __launch_bounds__(256) void reduce_multi_kernel(const ReduceItem* __r
             __syncthreads();
             if (kl == 0 && i < n4) {
                 float4 t = red[il];
-#pragma unroll
                 for (int q = 1; q < KL; ++q) { const float4 v = red[q * IL + il]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
                 t.x *= it.scale; t.y *= it.scale; t.z *= it.scale; t.w *= it.scale;
                 reinterpret_cast<float4*>(it.out)[i] = t;
