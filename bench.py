@@ -164,6 +164,7 @@ def main():
             a[1] += e0.elapsed_time(e1) * 1e-3
             a[2] += 1
         ops.PROFILE = None
+        p.engine.use_side_stream = True
         names = {0: 'conv_igemm_kernel<128, 64, 32, 32, 2>', 1: 'conv_igemm_kernel<64, 64, 32, 32, 2>',
                  2: 'conv_igemm_kernel<32, 32, 32, 16, 2>', 3: 'conv_igemm_kernel<64, 32, 32, 16, 2>',
                  4: 'conv_igemm_kernel<128, 16, 16, 16, 4>', 5: 'conv_igemm_kernel<64, 32, 16, 16, 2>',
@@ -178,8 +179,13 @@ def main():
         (kind, cfg), (fl, tt, cnt) = max(agg.items(), key=lambda kv: kv[1][1])
         all_fl = sum(a[0] for a in agg.values())
         all_t = sum(a[1] for a in agg.values())
+        traffic = None
+        try:  # L2-miss bytes per launch of this kernel from the committed rocprofv3 PMC passes (profiles/)
+            traffic = json.load(open(ROOT / 'profiles' / 'pmc_traffic.json'))[names[cfg]]['traffic_bytes_per_launch']
+        except Exception:
+            pass
         roof = {'bound': 'mfma', 'achieved': round(fl / tt / 1e12, 2), 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': round(fl / tt / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': None,
+                'frac': round(fl / tt / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': traffic,
                 'kernel': names[cfg], 'launches_per_step': cnt,
                 'avg_launch_us': round(tt / cnt * 1e6, 2), 'flops_per_launch_avg': fl / cnt,
                 'all_conv_launches': {'achieved': round(all_fl / all_t / 1e12, 2), 'time_ms_per_step': round(all_t * 1e3, 3),

@@ -30,6 +30,7 @@ struct PatchK {
     int B, Hi, Wi, Ca, Cb, Ho, Wo, Cout;
     int pad, pad_mode, ups, act;
     int tilesX, tilesY, tilesN, nblk;
+    int n_fastest;   // block order inside an XCD: 1 = the output-channel tiles of one spatial tile are adjacent
 };
 
 // RUN = true ("run tiles", for narrow images such as the 6x20 / 12x40 layers where a 4x16 rectangle
@@ -59,11 +60,17 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(PatchK p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm0 = (wave / WGN) * WM, wn0 = (wave % WGN) * WN;
 
+    // Consecutive logical ids share an XCD (and its 4 MiB L2).  With small weight tensors the BN-channel
+    // tiles of ONE spatial tile are made adjacent, so its input patch is fetched from HBM/MALL once and
+    // re-read from L2 by the other tiles; with large weights (layer3/4) the spatial tiles of one channel
+    // tile are adjacent instead (the weight slab stays in L2, the small input does anyway).
     int logical = xcd_remap((int)blockIdx.x, p.nblk);
+    int tn;
+    if (p.n_fastest) { tn = logical % p.tilesN; logical /= p.tilesN; }
     const int tx = logical % p.tilesX; logical /= p.tilesX;
     const int ty = logical % p.tilesY; logical /= p.tilesY;
     const int b = logical % p.B;
-    const int tn = logical / p.B;
+    if (!p.n_fastest) tn = logical / p.B;
     const int n0 = tn * BN;
     // rectangle tiles: (oy0, ox0) origin, compile-time patch width; run tiles: pixel run [m0, m0+BM)
     const int m0 = tx * BM;                                         // RUN only
@@ -241,6 +248,8 @@ static int launch_patch(PatchK k, hipStream_t stream) {
     k.tilesY = RUN ? 1 : cdiv(k.Ho, TH);
     k.tilesN = cdiv(k.Cout, BN);
     k.nblk = k.tilesX * k.tilesY * k.tilesN * k.B;
+    k.n_fastest = ((size_t)k.Cout * 9 * (k.Ca + k.Cb) * 4 <= (size_t)(2 << 20)) ? 1 : 0;
+    if (const char* e = getenv("CLSLAM_N_FASTEST")) k.n_fastest = atoi(e);
     hipLaunchKernelGGL((conv3x3_patch_kernel<TH, TW, BN, BK, MF, WGM, RUN, LDPAD, S>), dim3(k.nblk), dim3(256), 0, stream, k);
     return check_launch("conv3x3_patch");
 }
@@ -261,7 +270,7 @@ int conv3x3_patch_dispatch(const clslam_conv_desc* d, int cfg, hipStream_t strea
     k.residual = d->residual; k.actgrad_src = d->actgrad_src; k.out = d->out; k.actgrad_kind = d->actgrad_kind;
     k.B = d->batch; k.Hi = d->in_h; k.Wi = d->in_w; k.Ca = d->ch_a; k.Cb = d->ch_b; k.Ho = d->out_h; k.Wo = d->out_w;
     k.Cout = d->ch_out; k.pad = d->pad; k.pad_mode = d->pad_mode; k.ups = d->upsample_a; k.act = d->act;
-    k.tilesX = k.tilesY = k.tilesN = k.nblk = 0;
+    k.tilesX = k.tilesY = k.tilesN = k.nblk = 0; k.n_fastest = 0;
     switch (cfg) {
         case 10: return launch_patch<8, 16, 64, 16, 32, 2>(k, stream);   // 128 px x 64 ch, 32x32x2
         case 11: return launch_patch<8, 16, 32, 16, 32, 4>(k, stream);   // 128 px x 32 ch
