@@ -1,0 +1,89 @@
+"""The predictor used exactly the way the reference's SLAM driver uses it (slam/slam.py:39-40,
+143-147,174-192,229,266-270,296), plus the API corners of adapt()/predict()."""
+import numpy as np
+import pytest
+import torch
+
+from clslam_hip import synth
+from emu_util import BACKENDS, use_backend
+from helpers import make_oracle, rel_err
+from predictor_util import make_predictor
+
+H, W = 64, 128
+
+
+def _cat_dict(d1, d2):  # slam/slam.py:300-309
+    return {k: torch.cat([d1[k], d2[k]]) for k in d1 if k in d2}
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_slam_step_sequence(backend, tmp_path):
+    use_backend(backend)
+    B = 3
+    p = make_predictor(H, W, B, log_path=str(tmp_path))
+    online = synth.make_batch(1, H, W, seed=21)
+    online['relative_pose', 1] = torch.eye(4).unsqueeze(0)       # extra keys the dataset adds; dropped by _cat_dict
+    replay = synth.make_batch(2, H, W, seed=22)
+    # slam.py:143-147
+    p._set_eval()
+    with torch.no_grad():
+        img = online['rgb', 0, 0].to(p.device)
+        feat = p.models['depth_encoder'](img)[4].detach()
+        feat = feat.mean(-1).mean(-1).cpu().numpy()
+    assert feat.shape == (1, 512)
+    training = _cat_dict(online, replay)
+    assert 'relative_pose' not in [k[0] for k in training if isinstance(k, tuple)]
+    # slam.py:174-192, adaptation_epochs = 5 in the shipped config -> use 2 here
+    outputs, losses = p.adapt(online, training, steps=2)
+    T = outputs['cam_T_cam', 0, 1][0, :]
+    T = torch.linalg.inv(T).squeeze().cpu().detach().numpy()
+    assert T.shape == (4, 4) and np.isfinite(T).all()
+    losses = {k: float(v.squeeze().cpu().detach().numpy()) for k, v in losses.items()}
+    assert set(losses) >= {'depth_loss', 'velocity_loss', 'loss'} and losses['depth_loss'] == losses['loss']
+    # the caller's dict was moved to the device in place (dpp.py:916-917)
+    assert training['rgb', 0, 0].device.type == p.device.type
+    # slam.py:266-270
+    depth = outputs['depth', 0][0].cpu()
+    assert depth.shape == (1, H, W) and float(depth.min()) >= p.min_depth * 0.999
+    # slam.py:178 (adaptation disabled): forward only, batch of 1 while batch_size == 3
+    o2, l2 = p.adapt(online, None)
+    assert o2['depth', 0].shape == (1, 1, H, W) and torch.isfinite(l2['loss']).all()
+    # slam.py:229
+    Tlc, cov = p.predict_pose(online['rgb', 1, 0][0], replay['rgb', 1, 0][0], as_numpy=True)
+    assert Tlc.shape == (4, 4) and cov.shape == (6, 6)
+    # slam.py:296
+    p.save_model()
+    assert (tmp_path / 'models' / 'weights_000' / 'pose_decoder.pth').exists()
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_api_corners_match_oracle(backend):
+    """max_depth set, batch of 1 under a configured batch_size of 2 (weights broadcast-sum), predict()
+    after adapt(), online_loss_weight."""
+    use_backend(backend)
+    B = 2
+    p = make_predictor(H, W, B, max_depth=80.0)
+    o = make_oracle(H, W, B, max_depth=80.0)
+    one = synth.make_batch(1, H, W, seed=31)
+    noise1 = synth.make_noise(1, H, W, seed=3)
+    p.set_tie_break_noise(noise1)
+    out, losses = p.adapt({k: v.clone() for k, v in one.items()}, None)
+    oo, ol = o.predict(one, noise1)
+    assert rel_err(out['depth', 0].cpu(), oo['depth', 0]) < 1e-4
+    assert float(out['depth', 0].max()) <= 80.0 * 1.001
+    for k in ('loss', 'velocity_loss', 'reprojection_loss/scale_2', 'smooth_loss/scale_1'):
+        assert abs(float(losses[k]) - float(ol[k])) <= 1e-4 * max(abs(float(ol[k])), 1e-3), k
+    # online_loss_weight (dpp.py:297-305): non-uniform sample weights
+    two = synth.make_batch(B, H, W, seed=32)
+    noise2 = synth.make_noise(B, H, W, seed=4)
+    p.set_tie_break_noise(noise2)
+    out, losses = p.adapt(None, {k: v.clone() for k, v in two.items()}, steps=1, online_loss_weight=0.7)
+    o.set_adapt()
+    oo, ol = o.process_batch(two, noise2, torch.tensor([0.7, 0.3]))
+    for k, v in ol.items():
+        assert abs(float(losses[k]) - float(v)) <= 1e-4 * max(abs(float(v)), 1e-3), k
+    # predict() afterwards runs on the adapted weights and returns the reference's key set
+    pred = p.predict({k: v.clone() for k, v in two.items()})
+    assert set(pred.keys()) == set(oo.keys())
+    with pytest.raises(RuntimeError):   # actual batch neither 1 nor batch_size
+        p.adapt(None, synth.make_batch(3, H, W, seed=1), steps=1)
