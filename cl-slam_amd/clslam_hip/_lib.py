@@ -72,6 +72,10 @@ _SIGNATURES = {
     'clslam_warp_bwd_blocks': [i32, i32],
     'clslam_automask_pyramid': [fptr, fptr, fptr, fptr, fptr, i32, i32, i32, i32, C.c_void_p],
     'clslam_disp_mean_pyramid': [C.POINTER(fptr), fptr, i32, i32, i32, C.c_void_p],
+    'clslam_photo_automask_pyramid': [fptr, fptr, fptr, fptr, fptr, fptr, fptr, i32, i32, i32, C.c_void_p],
+    'clslam_loss_bwd2_blocks': [i32, i32],
+    'clslam_loss_bwd2_pyramid': [C.POINTER(fptr), fptr, fptr, fptr, fptr, fptr, fptr, fptr, fptr, fptr, fptr, fptr, i32, i32, i32,
+                                 C.c_float, C.c_float, C.c_void_p],
     'clslam_loss_bwd_blocks': [i32, i32],
     'clslam_loss_bwd_pyramid': [C.POINTER(fptr), fptr, fptr, fptr, fptr, fptr, fptr, fptr, fptr, fptr, fptr, fptr, i32, i32, i32,
                                 C.c_float, C.c_float, C.c_void_p],

@@ -247,7 +247,6 @@ class Engine:
         ws.warped = E(4, 2, B, 3, H, W)
         ws.idsrc = E(2, B, 3, H, W)
         ws.idmap = E(2, B, H, W)
-        ws.rpmap = E(4, 2, B, H, W)
         ws.coef = None  # allocated on the first training step
         ws.sel = torch.empty(4, B, H, W, dtype=torch.uint8, device=dev)
         ws.nblk = ops.automask_blocks(H, W)
@@ -278,9 +277,9 @@ class Engine:
         dev, H, W, B = self.device, self.H, self.W, ws.B
         E = lambda *s: torch.empty(*s, device=dev)  # noqa: E731
         t = SimpleNamespace()
-        ws.coef = E(4, 2, B, 9, H, W)
+        ws.coef = E(4, B, 9, H, W)       # SSIM coefficients of the selected frame per pixel
         t.ddisp_up = E(4, B, H, W)
-        t.nb2 = ops.loss_bwd_blocks(H, W)
+        t.nb2 = ops.loss_bwd2_blocks(H, W)
         t.dp_partial = E(4, B, t.nb2, 24)
         t.dz_disp = [torch.empty(B, H >> s, W >> s, device=dev) for s in range(4)]
         t.dpose = E(2 * B, 12)
@@ -419,9 +418,10 @@ class Engine:
             have_noise = True
         else:
             have_noise = False
-        # the four scales are contiguous along the leading dim: one launch each (8B "images" vs target n % B)
-        ops.photo_map(ws.warped, rgb[0], ws.rpmap, ws.coef if train else None, 8 * B, B, H, W)
-        ops.automask_pyramid(ws.idmap, ws.noise if have_noise else None, ws.rpmap, ws.sel, ws.partial, B, H, W)
+        # all four scales in one launch; reprojection maps stay in registers, only the selected frame's
+        # SSIM coefficients are kept for the backward
+        ops.photo_automask_pyramid(ws.warped, rgb[0], ws.idmap, ws.noise if have_noise else None, ws.sel,
+                                   ws.coef if train else None, ws.partial, B, H, W)
         ops.disp_mean_pyramid(ws.disp, ws.means, H, W)
         n_smooth = 0 if smooth_w is None else int(smooth_w.numel())
         if n_smooth and not (n_smooth < (W >> 3) - 1):
@@ -517,8 +517,8 @@ class Engine:
         H, W = self.H, self.W
         feats = ws.dfeats
         # loss -> disparity logits and pose-decoder output ----------------------------------------
-        ops.loss_bwd_pyramid(ws.disp, ws.sel, ws.coef, ws.warped, c.rgb[0], c.rgb[-1], c.rgb[1], c.Kinv, ws.P, c.sample_w,
-                             t.ddisp_up, t.dp_partial, self.min_depth, self.max_depth)
+        ops.loss_bwd2_pyramid(ws.disp, ws.sel, ws.coef, ws.warped, c.rgb[0], c.rgb[-1], c.rgb[1], c.Kinv, ws.P, c.sample_w,
+                              t.ddisp_up, t.dp_partial, self.min_depth, self.max_depth)
         ops.disp_grad_pyramid(t.ddisp_up, ws.disp, c.aux if c.n_smooth else None, c.n_smooth, t.dz_disp, H, W)
         ops.pose_bwd(t.dp_partial, 4, t.nb2, ws.pose, c.K, c.d0, c.d1, c.sample_w, self.vel_scale, t.dpose)
         side = self.side_stream if (self.use_side_stream and self.side_stream is not None) else None

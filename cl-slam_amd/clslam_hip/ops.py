@@ -357,3 +357,20 @@ def loss_bwd_pyramid(disps, sel, coef, warped, target, src_m1, src_p1, inv_k, pr
 def disp_grad_pyramid(ddisp_up, disps, smooth_aux, n_smooth, dzs, H, W):
     _lib.get_lib().call('clslam_disp_grad_pyramid', _p(ddisp_up), _ptr4(disps), _p(smooth_aux), n_smooth, _ptr4(dzs),
                         disps[0].shape[0], H, W, _stream(ddisp_up))
+
+
+def photo_automask_pyramid(warped, target, idmap, noise, sel, coef_sel, partial, batch, H, W):
+    _lib.get_lib().call('clslam_photo_automask_pyramid', _p(warped), _p(target), _p(idmap), _p(noise), _pa(sel, torch.uint8),
+                        _p(coef_sel), _p(partial), batch, H, W, _stream(warped))
+
+
+def loss_bwd2_blocks(H, W) -> int:
+    return _lib.get_lib().cdll.clslam_loss_bwd2_blocks(H, W)
+
+
+def loss_bwd2_pyramid(disps, sel, coef_sel, warped, target, src_m1, src_p1, inv_k, proj, sample_w, ddisp_up, dp_partial,
+                      min_depth, max_depth):
+    B, H, W = ddisp_up.shape[1], ddisp_up.shape[-2], ddisp_up.shape[-1]
+    _lib.get_lib().call('clslam_loss_bwd2_pyramid', _ptr4(disps), _pa(sel, torch.uint8), _p(coef_sel), _p(warped), _p(target),
+                        _p(src_m1), _p(src_p1), _p(inv_k), _p(proj), _p(sample_w), _p(ddisp_up), _p(dp_partial), B, H, W,
+                        _nd(min_depth), _nd(max_depth), _stream(ddisp_up))

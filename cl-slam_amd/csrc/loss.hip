@@ -16,6 +16,221 @@ namespace clslam {
 
 __device__ __forceinline__ int refl(int i, int n) { return reflect_idx(i, n); }
 
+// SSIM+L1 map value of one pixel for one (pred, target) image pair; optionally the 9 derivative
+// coefficients (alpha, beta, gamma per channel) described at photo_map_kernel.
+__device__ __forceinline__ float photo_px(const float* __restrict__ pred_n, const float* __restrict__ target_b, int H, int W,
+                                          int y, int x, float* coef9) {
+    const float C1 = 0.0001f, C2 = 0.0009f;
+    const size_t HW = (size_t)H * W;
+    int ys[3], xs[3];
+    for (int k = 0; k < 3; ++k) { ys[k] = refl(y + k - 1, H); xs[k] = refl(x + k - 1, W); }
+    float ssim_sum = 0.f, l1_sum = 0.f;
+    for (int c = 0; c < 3; ++c) {
+        const float* pp = pred_n + (size_t)c * HW;
+        const float* tp = target_b + (size_t)c * HW;
+        float sx = 0.f, sy = 0.f, sxx = 0.f, syy = 0.f, sxy = 0.f;
+        for (int ky = 0; ky < 3; ++ky)
+            for (int kx = 0; kx < 3; ++kx) {
+                const float xv = pp[ys[ky] * W + xs[kx]], yv = tp[ys[ky] * W + xs[kx]];
+                sx += xv; sy += yv; sxx += xv * xv; syy += yv * yv; sxy += xv * yv;
+            }
+        const float mu_x = sx / 9.f, mu_y = sy / 9.f;
+        const float sig_x = sxx / 9.f - mu_x * mu_x, sig_y = syy / 9.f - mu_y * mu_y, sig_xy = sxy / 9.f - mu_x * mu_y;
+        const float n1 = 2.f * mu_x * mu_y + C1, n2 = 2.f * sig_xy + C2;
+        const float d1 = mu_x * mu_x + mu_y * mu_y + C1, d2 = sig_x + sig_y + C2;
+        const float d = d1 * d2;
+        const float S = (n1 * n2) / d;
+        const float raw = (1.f - S) / 2.f;
+        ssim_sum += fminf(fmaxf(raw, 0.f), 1.f);
+        l1_sum += fabsf(tp[y * W + x] - pp[y * W + x]);
+        if (coef9) {
+            const float kf = (raw >= 0.f && raw <= 1.f) ? (0.85f / 3.f) * (-0.5f) / 9.f : 0.f;
+            coef9[c * 3 + 0] = kf * ((2.f * mu_y * (n2 - n1)) / d - S * (2.f * mu_x * (d2 - d1)) / d);
+            coef9[c * 3 + 1] = kf * (-2.f * S * d1 / d);
+            coef9[c * 3 + 2] = kf * (2.f * n1 / d);
+        }
+    }
+    return 0.85f * (ssim_sum / 3.f) + 0.15f * (l1_sum / 3.f);
+}
+
+// Fused photometric map + auto-masking for the whole pyramid (one launch, grid (nblk, B, nscale)):
+// both reprojection maps of a pixel are evaluated in registers, the 4-way min / argmin is taken against
+// the (scale-independent) identity maps + noise, and ONLY the selected frame's 9 SSIM coefficients are
+// stored (coef_sel (S,B,9,H,W)); no reprojection maps, no per-frame coefficient planes in HBM.
+__global__ __launch_bounds__(256) void photo_automask_kernel(const float* __restrict__ warped_all, const float* __restrict__ target,
+                                                             const float* __restrict__ idmap, const float* __restrict__ noise_all,
+                                                             unsigned char* __restrict__ sel_all, float* __restrict__ coef_sel_all,
+                                                             float* __restrict__ partial_all, int B, int H, int W,
+                                                             int pix_per_block) {
+    __shared__ float red[4];
+    const int b = blockIdx.y, sc = blockIdx.z;
+    const int HW = H * W;
+    const float* warped = warped_all + (size_t)sc * 2 * B * 3 * HW;
+    const float* noise = noise_all ? noise_all + (size_t)sc * B * 2 * HW : nullptr;
+    unsigned char* sel = sel_all + ((size_t)sc * B + b) * HW;
+    float* coef_sel = coef_sel_all ? coef_sel_all + ((size_t)sc * B + b) * 9 * HW : nullptr;
+    const int p0 = blockIdx.x * pix_per_block, p1 = min(HW, p0 + pix_per_block);
+    float s = 0.f;
+    for (int p = p0 + (int)threadIdx.x; p < p1; p += 256) {
+        const int x = p % W, y = p / W;
+        float c0 = idmap[((size_t)0 * B + b) * HW + p];
+        float c1 = idmap[((size_t)1 * B + b) * HW + p];
+        if (noise) { c0 += noise[((size_t)b * 2 + 0) * HW + p]; c1 += noise[((size_t)b * 2 + 1) * HW + p]; }
+        float k2[9], k3[9];
+        const float c2 = photo_px(warped + ((size_t)0 * B + b) * 3 * HW, target + (size_t)b * 3 * HW, H, W, y, x, coef_sel ? k2 : nullptr);
+        const float c3 = photo_px(warped + ((size_t)1 * B + b) * 3 * HW, target + (size_t)b * 3 * HW, H, W, y, x, coef_sel ? k3 : nullptr);
+        float m = c0; int k = 0;
+        if (c1 < m) { m = c1; k = 1; }
+        if (c2 < m) { m = c2; k = 2; }
+        if (c3 < m) { m = c3; k = 3; }
+        sel[p] = (unsigned char)k;
+        if (coef_sel && k >= 2) {
+#pragma unroll
+            for (int q = 0; q < 9; ++q) coef_sel[(size_t)q * HW + p] = (k == 2) ? k2[q] : k3[q];
+        }
+        s += m;
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial_all[((size_t)sc * B + b) * gridDim.x + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// Loss backward v2 for the whole pyramid, LDS-tiled: a block owns an 8 x 64 pixel tile of one (scale,
+// sample); sel and the selected-frame coefficients of the tile + 1-pixel halo are staged once in LDS
+// (every neighbour a pixel needs -- incl. the reflection fold -- lies in its 3x3 neighbourhood), then each
+// thread does the transposed SSIM stencil from LDS and the grid_sample / projection / depth backward.
+constexpr int LB_TH = 8, LB_TW = 64, LB_PH = LB_TH + 2, LB_PW = LB_TW + 2;
+__global__ __launch_bounds__(256) void loss_bwd2_kernel(Pyramid pyr, const unsigned char* __restrict__ sel_all,
+                                                        const float* __restrict__ coef_sel_all, const float* __restrict__ warped_all,
+                                                        const float* __restrict__ target, const float* __restrict__ src_m1,
+                                                        const float* __restrict__ src_p1, const float* __restrict__ Kinv,
+                                                        const float* __restrict__ P, const float* __restrict__ sample_w,
+                                                        float* __restrict__ ddisp_up_all, float* __restrict__ dP_partial, int B,
+                                                        int H, int W, float da, float db, int dmode, int tilesX) {
+    __shared__ float cs[9][LB_PH * LB_PW];
+    __shared__ unsigned char ss[LB_PH * LB_PW];
+    __shared__ float red[4][24];
+    const int b = blockIdx.y, sc = blockIdx.z;
+    const int HW = H * W;
+    const int ty = blockIdx.x / tilesX, tx = blockIdx.x - ty * tilesX;
+    const int y0 = ty * LB_TH, x0 = tx * LB_TW;
+    const int h = pyr.h[sc], w = pyr.w[sc];
+    const float* disp_s = pyr.disp[sc];
+    const unsigned char* sl = sel_all + ((size_t)sc * B + b) * HW;
+    const float* coef = coef_sel_all + ((size_t)sc * B + b) * 9 * HW;
+    const float* warped = warped_all + (size_t)sc * 2 * B * 3 * HW;
+    float* ddisp_up = ddisp_up_all + (size_t)sc * B * HW;
+    const float wq = sample_w[b] / ((float)H * (float)W) / 4.f;
+    // ---- stage sel + coefficients (tile + halo; outside the image: sel = 255 -> never matches) -------------
+    for (int e = threadIdx.x; e < LB_PH * LB_PW; e += 256) {
+        const int r = e / LB_PW, c = e - r * LB_PW;
+        const int yy = y0 - 1 + r, xx = x0 - 1 + c;
+        const bool in = yy >= 0 && yy < H && xx >= 0 && xx < W;
+        const unsigned char sv = in ? sl[yy * W + xx] : (unsigned char)255;
+        ss[e] = sv;
+        const bool need = in && sv >= 2 && sv < 4;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) cs[q][e] = need ? coef[(size_t)q * HW + (size_t)yy * W + xx] : 0.f;
+    }
+    __syncthreads();
+    float dPacc[24];
+#pragma unroll
+    for (int k = 0; k < 24; ++k) dPacc[k] = 0.f;
+    const float* Ki = Kinv + (size_t)b * 16;
+#pragma unroll 1
+    for (int it = 0; it < (LB_TH * LB_TW) / 256; ++it) {
+        const int lp = threadIdx.x + it * 256;
+        const int ly = lp / LB_TW, lx = lp - ly * LB_TW;
+        const int y = y0 + ly, x = x0 + lx;
+        if (y >= H || x >= W) continue;
+        const int pi = y * W + x;
+        // transposed stencil: weights of the 3x3 neighbours incl. the reflection fold (rows/cols 0 and H-1 / W-1
+        // are counted twice for the second / second-to-last row / column)
+        float wy[3] = {1.f, 1.f, 1.f}, wx[3] = {1.f, 1.f, 1.f};
+        if (y == 1) wy[0] = 2.f;
+        if (y == H - 2) wy[2] = 2.f;
+        if (x == 1) wx[0] = 2.f;
+        if (x == W - 2) wx[2] = 2.f;
+        float sA[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}}, sB[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}},
+              sC[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int e = (ly + dy) * LB_PW + lx + dx;
+                const unsigned char sv = ss[e];
+                if (sv < 2 || sv > 3) continue;
+                const float ww = wy[dy] * wx[dx];
+                const int fi = sv - 2;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    sA[fi][c] += ww * cs[c * 3 + 0][e];
+                    sB[fi][c] += ww * cs[c * 3 + 1][e];
+                    sC[fi][c] += ww * cs[c * 3 + 2][e];
+                }
+            }
+        const unsigned char own = ss[(ly + 1) * LB_PW + lx + 1];
+        const float disp = upsample_disp(disp_s + (size_t)b * h * w, h, w, H, W, y, x);
+        const float dep = disp_to_depth_dev(disp, da, db, dmode);
+        const float fx = (float)x, fy = (float)y;
+        float cam[3], X[3];
+        for (int i = 0; i < 3; ++i) { cam[i] = Ki[i * 4 + 0] * fx + Ki[i * 4 + 1] * fy + Ki[i * 4 + 2]; X[i] = dep * cam[i]; }
+        float ddepth = 0.f;
+#pragma unroll
+        for (int fi = 0; fi < 2; ++fi) {
+            const int n = fi * B + b;
+            const float* Pm = P + (size_t)n * 12;
+            float p[3];
+            for (int i = 0; i < 3; ++i) p[i] = Pm[i * 4 + 0] * X[0] + Pm[i * 4 + 1] * X[1] + Pm[i * 4 + 2] * X[2] + Pm[i * 4 + 3];
+            const float den = p[2] + 1e-7f;
+            const float u = p[0] / den, v = p[1] / den;
+            const Sample s = sample_coords(u, v, H, W);
+            const float wx1 = s.ix - (float)s.x0, wy1 = s.iy - (float)s.y0;
+            const float wx0 = (float)(s.x0 + 1) - s.ix, wy0 = (float)(s.y0 + 1) - s.iy;
+            const bool x1ok = s.x0 + 1 < W, y1ok = s.y0 + 1 < H;
+            const float* src = (fi == 0 ? src_m1 : src_p1) + (size_t)b * 3 * HW;
+            float gix = 0.f, giy = 0.f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float xv = warped[((size_t)n * 3 + c) * HW + pi];
+                const float yv = target[((size_t)b * 3 + c) * HW + pi];
+                float g = sA[fi][c] + sB[fi][c] * xv + sC[fi][c] * yv;
+                if (own == 2 + fi) g += (0.15f / 3.f) * (xv > yv ? 1.f : (xv < yv ? -1.f : 0.f));
+                g *= wq;
+                const float* pl = src + (size_t)c * HW;
+                const float nw = pl[s.y0 * W + s.x0];
+                const float ne = x1ok ? pl[s.y0 * W + s.x0 + 1] : 0.f;
+                const float sw = y1ok ? pl[(s.y0 + 1) * W + s.x0] : 0.f;
+                const float se = (x1ok && y1ok) ? pl[(s.y0 + 1) * W + s.x0 + 1] : 0.f;
+                gix += g * (-nw * wy0 + ne * wy0 - sw * wy1 + se * wy1);
+                giy += g * (-nw * wx0 - ne * wx1 + sw * wx0 + se * wx1);
+            }
+            const float du = gix * s.mx, dv = giy * s.my;
+            float dp[3];
+            dp[0] = du / den; dp[1] = dv / den; dp[2] = -(du * u + dv * v) / den;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                dPacc[fi * 12 + i * 4 + 0] += dp[i] * X[0]; dPacc[fi * 12 + i * 4 + 1] += dp[i] * X[1];
+                dPacc[fi * 12 + i * 4 + 2] += dp[i] * X[2]; dPacc[fi * 12 + i * 4 + 3] += dp[i];
+            }
+            for (int j = 0; j < 3; ++j)
+                ddepth += (Pm[0 * 4 + j] * dp[0] + Pm[1 * 4 + j] * dp[1] + Pm[2 * 4 + j] * dp[2]) * cam[j];
+        }
+        ddisp_up[(size_t)b * HW + pi] = (dmode == 2) ? -db * dep * dep * ddepth : -dep / disp * ddepth;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 24; ++k) {
+        const float s = wave_sum(dPacc[k]);
+        if (lane == 0) red[wave][k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 24)
+        dP_partial[(((size_t)sc * B + b) * gridDim.x + blockIdx.x) * 24 + threadIdx.x] =
+            red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
 // ------------------------------------------------------------------------------------------------
 // map[n,y,x] = 0.85*mean_c ssim_c + 0.15*mean_c |t-p|  for pred image n (N = npred images, each
 // (3,H,W)) against target image (n % B).  When coef != NULL also stores, per channel c, the three
@@ -512,6 +727,39 @@ extern "C" int clslam_disp_mean_pyramid(const float* const* disp, float* psum, i
     hipLaunchKernelGGL(disp_mean_kernel, dim3(DM_CHUNKS, batch, 4), dim3(256), 0, (hipStream_t)stream, make_pyramid(disp, H, W),
                        psum, batch);
     return check_launch("disp_mean_pyramid");
+}
+
+// Fused photometric map + automask over the pyramid: warped (4,2,B,3,H,W), idmap (2,B,H,W), noise (4,B,2,H,W)|NULL ->
+// sel (4,B,H,W), coef_sel (4,B,9,H,W)|NULL (training only), partial (4,B,clslam_automask_blocks).
+extern "C" int clslam_photo_automask_pyramid(const float* warped, const float* target, const float* idmap, const float* noise,
+                                             unsigned char* sel, float* coef_sel, float* partial, int batch, int H, int W,
+                                             void* stream) {
+    CLSLAM_REQUIRE(warped && target && idmap && sel && partial && H >= 2 && W >= 2, "photo_automask_pyramid: bad args");
+    if (!batch) return CLSLAM_OK;
+    const int nblk = clslam_automask_blocks(H, W);
+    hipLaunchKernelGGL(photo_automask_kernel, dim3(nblk, batch, 4), dim3(256), 0, (hipStream_t)stream, warped, target, idmap, noise,
+                       sel, coef_sel, partial, batch, H, W, cdiv(H * W, nblk));
+    return check_launch("photo_automask_pyramid");
+}
+
+extern "C" int clslam_loss_bwd2_blocks(int H, int W) { return cdiv(H, LB_TH) * cdiv(W, LB_TW); }
+
+// LDS-tiled fused loss backward on the selected-frame coefficients (clslam_photo_automask_pyramid);
+// dp_partial [4][B][clslam_loss_bwd2_blocks][24].
+extern "C" int clslam_loss_bwd2_pyramid(const float* const* disp, const unsigned char* sel, const float* coef_sel,
+                                        const float* warped, const float* target, const float* src_m1, const float* src_p1,
+                                        const float* inv_k, const float* proj, const float* sample_w, float* ddisp_up,
+                                        float* dp_partial, int batch, int H, int W, float min_depth, float max_depth, void* stream) {
+    CLSLAM_REQUIRE(disp && sel && coef_sel && warped && target && src_m1 && src_p1 && inv_k && proj && sample_w && ddisp_up &&
+                   dp_partial, "loss_bwd2_pyramid: null");
+    float a, b; int mode;
+    depth_mode(min_depth, max_depth, &a, &b, &mode);
+    if (!batch) return CLSLAM_OK;
+    const int tilesX = cdiv(W, LB_TW);
+    hipLaunchKernelGGL(loss_bwd2_kernel, dim3(clslam_loss_bwd2_blocks(H, W), batch, 4), dim3(256), 0, (hipStream_t)stream,
+                       make_pyramid(disp, H, W), sel, coef_sel, warped, target, src_m1, src_p1, inv_k, proj, sample_w, ddisp_up,
+                       dp_partial, batch, H, W, a, b, mode, tilesX);
+    return check_launch("loss_bwd2_pyramid");
 }
 
 extern "C" int clslam_loss_bwd_blocks(int H, int W) { return std::max(1, std::min(256, cdiv(H * W, 1024))); }

@@ -191,6 +191,17 @@ int clslam_automask(const float* idmap, const float* noise, const float* rpmap, 
 int clslam_automask_pyramid(const float* idmap, const float* noise, const float* rpmap, unsigned char* sel, float* partial,
                             int nscale, int batch, int H, int W, void* stream);
 int clslam_disp_mean_pyramid(const float* const* disp, float* psum, int batch, int H, int W, void* stream);
+/* Fused clslam_photo_map(warped) + clslam_automask over the pyramid: both reprojection maps are evaluated in
+ * registers and only the SELECTED frame's 9 SSIM coefficients are stored: coef_sel (4,B,9,H,W) or NULL.      */
+int clslam_photo_automask_pyramid(const float* warped, const float* target, const float* idmap, const float* noise,
+                                  unsigned char* sel, float* coef_sel, float* partial, int batch, int H, int W,
+                                  void* stream);
+/* LDS-tiled fused loss backward on coef_sel; dp_partial [4][B][clslam_loss_bwd2_blocks][24].                */
+int clslam_loss_bwd2_blocks(int H, int W);
+int clslam_loss_bwd2_pyramid(const float* const* disp, const unsigned char* sel, const float* coef_sel, const float* warped,
+                             const float* target, const float* src_m1, const float* src_p1, const float* inv_k,
+                             const float* proj, const float* sample_w, float* ddisp_up, float* dp_partial, int batch,
+                             int H, int W, float min_depth, float max_depth, void* stream);
 /* Fused clslam_photo_grad + clslam_warp_bwd for all four scales: sel (4,B,H,W), coef (4,2,B,9,H,W),
  * warped (4,2,B,3,H,W) -> ddisp_up (4,B,H,W), dp_partial [4][B][clslam_loss_bwd_blocks][24].          */
 int clslam_loss_bwd_blocks(int H, int W);

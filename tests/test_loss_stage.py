@@ -37,10 +37,10 @@ def _run_loss_stage(dev, inputs, disp, pose, noise, sample_w, smooth_w, H, W, mi
     partial = torch.empty(4, B, nblk, device=dev)
     sel = torch.empty(4, B, H, W, dtype=torch.uint8, device=dev)
     means = torch.empty(4, B, ops.disp_mean_chunks(), device=dev)
-    if pyramid:
+    if pyramid:   # the engine's path: fused map+automask (selected-frame coefficients), LDS-tiled backward
         noise_all = torch.stack([t(noise[s]) for s in range(4)]).contiguous() if noise is not None else None
-        ops.photo_map(warped, src[0], rpmap, coef if train else None, 8 * B, B, H, W)
-        ops.automask_pyramid(idmap, noise_all, rpmap, sel, partial, B, H, W)
+        coef_sel = torch.empty(4, B, 9, H, W, device=dev) if train else None
+        ops.photo_automask_pyramid(warped, src[0], idmap, noise_all, sel, coef_sel, partial, B, H, W)
         ops.disp_mean_pyramid(disp_d, means, H, W)
     else:
         for s in range(4):
@@ -60,11 +60,11 @@ def _run_loss_stage(dev, inputs, disp, pose, noise, sample_w, smooth_w, H, W, mi
         return out
     dz = []
     if pyramid:
-        nb2 = ops.loss_bwd_blocks(H, W)
+        nb2 = ops.loss_bwd2_blocks(H, W)
         dp_partial = torch.empty(4, B, nb2, 24, device=dev)
         ddisp_all = torch.empty(4, B, H, W, device=dev)
-        ops.loss_bwd_pyramid(disp_d, sel, coef, warped, src[0], src[-1], src[1], Kinv, P, t(sample_w), ddisp_all, dp_partial,
-                             min_depth, max_depth)
+        ops.loss_bwd2_pyramid(disp_d, sel, coef_sel, warped, src[0], src[-1], src[1], Kinv, P, t(sample_w), ddisp_all, dp_partial,
+                              min_depth, max_depth)
         dz = [torch.empty_like(d) for d in disp_d]
         ops.disp_grad_pyramid(ddisp_all, disp_d, aux if n_smooth else None, n_smooth, dz, H, W)
     else:
