@@ -138,9 +138,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradK p) {
     const int mbeg = split * p.chunks_per_split * KM;
     const int mend = min(p.M, mbeg + p.chunks_per_split * KM);
 
-    for (int mc = mbeg; mc < mend; mc += KM) {
-        // ---- global -> registers ------------------------------------------------------------
-        float4 rz[Z_IT], rg[NT][G_IT];
+    // Software pipeline: chunk mc+KM is fetched global->registers while the MFMAs of chunk mc run; the
+    // zero masks are applied when the registers are written to LDS (see conv_patch.hip).
+    float4 rz[Z_IT], rg[NT][G_IT];
+    bool okz_[Z_IT], okg_[NT][G_IT];
+    auto load_chunk = [&](int mc) {
 #pragma unroll
         for (int it = 0; it < Z_IT; ++it) {
             const int f = tid + it * 256;
@@ -148,7 +150,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradK p) {
             const int m = mc + row;
             const bool okz = (f < Z_F4) && (m < mend);
             rz[it] = *reinterpret_cast<const float4*>(p.dz + (size_t)(okz ? m : 0) * p.Cout + co0 + (okz ? c4 * 4 : 0));
-            if (!okz) rz[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            okz_[it] = okz;
         }
 #pragma unroll
         for (int it = 0; it < G_IT; ++it) {
@@ -177,27 +179,37 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradK p) {
                 const size_t oa = ok ? ((size_t)(b * HA + sy) * WA + sx) * p.Ca : 0;
                 const size_t ob = ok ? ((size_t)(b * p.Hi + iy) * p.Wi + ix) * p.Cb : 0;
                 const float* ptr = (c < p.Ca) ? p.src_a + oa + c : p.src_b + ob + (c - p.Ca);
-                float4 v = *reinterpret_cast<const float4*>(ptr);   // unconditional, masked below
-                if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
-                rg[t][it] = v;
+                rg[t][it] = *reinterpret_cast<const float4*>(ptr);   // unconditional, masked at store time
+                okg_[t][it] = ok;
             }
         }
-        __syncthreads();  // previous chunk's MFMAs are done reading LDS
+    };
+    auto store_chunk = [&]() {
 #pragma unroll
         for (int it = 0; it < Z_IT; ++it) {
             const int f = tid + it * 256;
-            if (f < Z_F4) *reinterpret_cast<float4*>(&Zs[(f / (COT / 4)) * LDZ + (f % (COT / 4)) * 4]) = rz[it];
+            float4 v = rz[it];
+            if (!okz_[it]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (f < Z_F4) *reinterpret_cast<float4*>(&Zs[(f / (COT / 4)) * LDZ + (f % (COT / 4)) * 4]) = v;
         }
 #pragma unroll
         for (int it = 0; it < G_IT; ++it) {
             const int f = tid + it * 256;
-            if (f < G_F4) {
 #pragma unroll
-                for (int t = 0; t < NT; ++t)
-                    *reinterpret_cast<float4*>(&Gs[t][(f / (CIT / 4)) * LDG + (f % (CIT / 4)) * 4]) = rg[t][it];
+            for (int t = 0; t < NT; ++t) {
+                float4 v = rg[t][it];
+                if (!okg_[t][it]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (f < G_F4) *reinterpret_cast<float4*>(&Gs[t][(f / (CIT / 4)) * LDG + (f % (CIT / 4)) * 4]) = v;
             }
         }
+    };
+
+    if (mbeg < mend) load_chunk(mbeg);
+    for (int mc = mbeg; mc < mend; mc += KM) {
+        __syncthreads();  // previous chunk's MFMAs are done reading LDS
+        store_chunk();
         __syncthreads();
+        if (mc + KM < mend) load_chunk(mc + KM);
         // ---- MFMA over the KM pixels of the chunk -------------------------------------------
 #pragma unroll
         for (int ks = 0; ks < KM / KG; ++ks) {

@@ -86,6 +86,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvK p) {
     }
 
     float4 ra[A_IT], rb[B_IT];
+    bool ra_ok[A_IT];   // zero masks of the chunk in flight, applied when it is written to LDS
     const int chunks_per_tap = Cin / BK;
     const int niter = taps * chunks_per_tap;
 
@@ -105,15 +106,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvK p) {
             } else {
                 ok = ok && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
             }
-            // unconditional load from a valid address, masked afterwards: a branch around the load would
-            // make the compiler wait vmcnt(0) at the join and serialise the prefetch
+            // unconditional load from a valid address; the zero mask is applied in store_lds, after the
+            // MFMAs of the current chunk (a branch around the load, or a mask right behind it, makes the
+            // compiler wait vmcnt(0) before the MFMA block and serialises the prefetch)
             const int sy = p.ups ? (iy >> 1) : iy, sx = p.ups ? (ix >> 1) : ix;
             const size_t oa = ok ? ((size_t)(a_b[it] * HA + sy) * WA + sx) * p.Ca : 0;
             const size_t ob = ok ? ((size_t)(a_b[it] * p.Hi + iy) * p.Wi + ix) * p.Cb : 0;
             const float* ptr = (c < p.Ca) ? p.src_a + oa + c : p.src_b + ob + (c - p.Ca);
-            float4 v = *reinterpret_cast<const float4*>(ptr);
-            if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
-            ra[it] = v;
+            ra[it] = *reinterpret_cast<const float4*>(ptr);
+            ra_ok[it] = ok;
         }
 #pragma unroll
         for (int it = 0; it < B_IT; ++it) {
@@ -121,23 +122,25 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvK p) {
             const int row = f / F4_ROW;
             const int n = n0 + row;
             const bool okb = (f < BN * F4_ROW) && (n < p.Cout);
-            float4 v = *reinterpret_cast<const float4*>(p.wgt + ((size_t)(okb ? n : 0) * taps + tap) * Cin + c0 + (f % F4_ROW) * 4);
-            if (!okb) v = make_float4(0.f, 0.f, 0.f, 0.f);
-            rb[it] = v;
+            rb[it] = *reinterpret_cast<const float4*>(p.wgt + ((size_t)(okb ? n : 0) * taps + tap) * Cin + c0 + (f % F4_ROW) * 4);
         }
     };
     auto store_lds = [&](int buf) {
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
             const int f = tid + it * 256;
+            float4 v = ra[it];
+            if (!ra_ok[it]) v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (f < BM * F4_ROW)
-                *reinterpret_cast<float4*>(&As[buf][(f / F4_ROW) * LDA + (f % F4_ROW) * 4]) = ra[it];
+                *reinterpret_cast<float4*>(&As[buf][(f / F4_ROW) * LDA + (f % F4_ROW) * 4]) = v;
         }
 #pragma unroll
         for (int it = 0; it < B_IT; ++it) {
             const int f = tid + it * 256;
+            float4 v = rb[it];
+            if (n0 + f / F4_ROW >= p.Cout) v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (f < BN * F4_ROW)
-                *reinterpret_cast<float4*>(&Bs[buf][(f / F4_ROW) * LDA + (f % F4_ROW) * 4]) = rb[it];
+                *reinterpret_cast<float4*>(&Bs[buf][(f / F4_ROW) * LDA + (f % F4_ROW) * 4]) = v;
         }
     };
 

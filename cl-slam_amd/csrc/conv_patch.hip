@@ -106,54 +106,68 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(PatchK p) {
         }
     }
 
+    // Prefetch loads are unconditional (out-of-image slots read pixel 0 of the image, out-of-range weight
+    // rows read row 0) and the zero mask is applied when the registers are written to LDS, AFTER the MFMA
+    // block of the current chunk.  Masking right after the load makes the compiler wait for the prefetch
+    // before the MFMAs (s_waitcnt vmcnt(0) ahead of the block): no load/compute overlap.
+    bool okP[P_IT], okW[W_IT];
+    const float* wptr[W_IT];
+#pragma unroll
+    for (int it = 0; it < P_IT; ++it) {
+        okP[it] = offA[it] >= 0;
+        if (!okP[it]) { offA[it] = 0; offB[it] = 0; }
+    }
+#pragma unroll
+    for (int it = 0; it < W_IT; ++it) {
+        const int f = tid + it * 256;
+        const int c4 = f % F4;
+        const int n = (f / F4) % BN;
+        const int tap = f / (F4 * BN);
+        okW[it] = (f < W_SLOTS) && (n0 + n < p.Cout);
+        wptr[it] = p.wgt + ((size_t)(okW[it] ? n0 + n : 0) * 9 + (okW[it] ? tap : 0)) * Cin + c4 * 4;
+    }
     float4 rp[P_IT], rw[W_IT];
     auto load_global = [&](int c0) {
 #pragma unroll
         for (int it = 0; it < P_IT; ++it) {
             const int f = tid + it * 256;
             const int c = c0 + (f % F4) * 4;
-            // unconditional load from a valid address, masked afterwards (no branch around the load)
-            const bool fromA = c < p.Ca;
-            const bool ok = offA[it] >= 0;
-            const float* ptr = fromA ? p.src_a + (ok ? offA[it] : 0) + c : p.src_b + (ok ? offB[it] : 0) + (c - p.Ca);
-            float4 v = *reinterpret_cast<const float4*>(ptr);
-            if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
-            rp[it] = v;
+            const float* ptr = c < p.Ca ? p.src_a + offA[it] + c : p.src_b + offB[it] + (c - p.Ca);
+            rp[it] = *reinterpret_cast<const float4*>(ptr);
         }
 #pragma unroll
-        for (int it = 0; it < W_IT; ++it) {
-            const int f = tid + it * 256;
-            const int c4 = f % F4;
-            const int n = (f / F4) % BN;
-            const int tap = f / (F4 * BN);
-            const bool ok = (f < W_SLOTS) && (n0 + n < p.Cout);
-            const float* ptr = p.wgt + ((size_t)(ok ? n0 + n : 0) * 9 + (ok ? tap : 0)) * Cin + c0 + c4 * 4;
-            float4 v = *reinterpret_cast<const float4*>(ptr);
-            if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
-            rw[it] = v;
-        }
+        for (int it = 0; it < W_IT; ++it) rw[it] = *reinterpret_cast<const float4*>(wptr[it] + c0);
     };
     auto store_lds = [&]() {
 #pragma unroll
         for (int it = 0; it < P_IT; ++it) {
             const int f = tid + it * 256;
-            if (f < P_SLOTS) *reinterpret_cast<float4*>(&Ps[(f / F4) * LD + (f % F4) * 4]) = rp[it];
+            float4 v = rp[it];
+            if (!okP[it]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (f < P_SLOTS) *reinterpret_cast<float4*>(&Ps[(f / F4) * LD + (f % F4) * 4]) = v;
         }
 #pragma unroll
         for (int it = 0; it < W_IT; ++it) {
             const int f = tid + it * 256;
-            if (f < W_SLOTS) *reinterpret_cast<float4*>(&Wsm[(f / F4) * LD + (f % F4) * 4]) = rw[it];
+            float4 v = rw[it];
+            if (!okW[it]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (f < W_SLOTS) *reinterpret_cast<float4*>(&Wsm[(f / F4) * LD + (f % F4) * 4]) = v;
         }
     };
 
     typedef float accv __attribute__((ext_vector_type(NACC)));
-    accv acc[TM][TN];
+    // A wave with a single MFMA tile would issue one serially dependent accumulator chain (each MFMA
+    // waits ~8 extra cycles for the previous result); two interleaved chains keep the pipe full.
+    constexpr int NCH = (TM * TN == 1) ? 2 : 1;
+    accv acc[TM][TN][NCH];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int r = 0; r < NACC; ++r) acc[i][j][r] = 0.f;
+            for (int h = 0; h < NCH; ++h)
+#pragma unroll
+                for (int r = 0; r < NACC; ++r) acc[i][j][h][r] = 0.f;
 
     const int frow = lane % MF, kg = lane / MF;
     // LDS row of this lane's pixel for tap (0,0), per M tile
@@ -195,8 +209,9 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(PatchK p) {
 #pragma unroll
                         for (int j = 0; j < TN; ++j) {
                             const float bv = t == 0 ? fb[j].x : t == 1 ? fb[j].y : t == 2 ? fb[j].z : fb[j].w;
-                            if constexpr (MF == 32) acc[i][j] = mfma_32x32x2(av, bv, acc[i][j]);
-                            else acc[i][j] = mfma_16x16x4(av, bv, acc[i][j]);
+                            accv& a = acc[i][j][t % NCH];
+                            if constexpr (MF == 32) a = mfma_32x32x2(av, bv, a);
+                            else a = mfma_16x16x4(av, bv, a);
                         }
                     }
                 }
@@ -228,7 +243,7 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(PatchK p) {
                     if (oy >= p.Ho || ox >= p.Wo) continue;
                 }
                 const size_t o = (((size_t)b * p.Ho + oy) * p.Wo + ox) * p.Cout + n;
-                float v = acc[i][j][r] * sc + sh;
+                float v = (NCH == 2 ? acc[i][j][0][r] + acc[i][j][NCH - 1][r] : acc[i][j][0][r]) * sc + sh;
                 if (p.residual) v += p.residual[o];
                 v = apply_act(v, p.act);
                 if (p.actgrad_src) v *= act_grad_from_output(p.actgrad_src[o], p.actgrad_kind);

@@ -9,8 +9,11 @@
 // it, as in conv_patch.hip) and runs all 9 taps from it.  MFMA v_mfma_f32_16x16x4_f32 with the PIXEL
 // index as the reduction dimension: lane group g = lane/16 feeds pixel 4*step+g, a = dZ[p][co],
 // b = patch[p + tap][ci]; both are conflict-free ds_read_b32 (row stride = 16 mod 32 banks).
-// Wave w owns taps {w, w+4, w+8}; accumulators stay in registers across the block's whole tile range
-// and are written once as this split's partial (reduced by clslam_reduce_partials, deterministic).
+// The four waves split the REDUCTION axis: wave w takes the pixel quads ks = w (mod 4) of every tile and
+// accumulates all 9 taps (9 x TI x TJ MFMA tiles in registers, no per-wave tap ownership and hence no
+// 3/2/2/2 imbalance or exec-masked MFMAs).  Accumulators stay in registers across the block's whole tile
+// range; at the end the four waves' copies are summed in wave order through LDS and written once as
+// this split's partial (reduced by clslam_reduce_partials / clslam_reduce_multi, deterministic).
 #include "common.h"
 
 namespace clslam {
@@ -48,9 +51,12 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_patch_kernel(WgPatchK p) {
     const int csrc = fromA ? ci0 : ci0 - p.Ca;
     const int Csrc = fromA ? p.Ca : p.Cb;
 
-    f32x4 acc[3][TI][TJ];
+    static_assert(4 * TI * TJ * 256 <= BM * LDZ, "cross-wave reduction buffer aliases Zs");
+    const float* __restrict__ src = fromA ? p.src_a : p.src_b;   // hoisted: selecting inside the tile loop
+                                                                 // re-loads the pointer from the kernarg
+    f32x4 acc[9][TI][TJ];
 #pragma unroll
-    for (int t = 0; t < 3; ++t)
+    for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int i = 0; i < TI; ++i)
 #pragma unroll
@@ -62,14 +68,17 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_patch_kernel(WgPatchK p) {
     const int t_beg = split * p.tiles_per_split;
     const int t_end = min(p.ntiles, t_beg + p.tiles_per_split);
 
-    for (int tile = t_beg; tile < t_end; ++tile) {
+    // Software pipeline: the next tile's dZ tile and input patch are fetched global->registers while the
+    // MFMAs of the current tile run; zero masks are applied when the registers go to LDS (masking right
+    // after the load would make the compiler wait for the prefetch before the MFMA block).
+    float4 rz[Z_IT], rp[P_IT];
+    bool okz[Z_IT], okp[P_IT];
+    auto load_tile = [&](int tile) {
         int q = tile;
         const int tx = q % p.tilesX; q /= p.tilesX;
         const int ty = q % p.tilesY; q /= p.tilesY;
         const int b = q;
         const int oy0 = ty * TH, ox0 = tx * TW;
-        // ---- global -> registers ----------------------------------------------------------------
-        float4 rz[Z_IT], rp[P_IT];
 #pragma unroll
         for (int it = 0; it < Z_IT; ++it) {
             const int f = tid + it * 256;
@@ -78,7 +87,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_patch_kernel(WgPatchK p) {
             const bool ok = (f < Z_F4) && oy < p.Ho && ox < p.Wo;
             const size_t o = ok ? (((size_t)b * p.Ho + oy) * p.Wo + ox) * p.Cout + co0 + c4 * 4 : 0;
             rz[it] = *reinterpret_cast<const float4*>(p.dz + o);
-            if (!ok) rz[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            okz[it] = ok;
         }
 #pragma unroll
         for (int it = 0; it < P_IT; ++it) {
@@ -102,61 +111,83 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_patch_kernel(WgPatchK p) {
                     o = ((size_t)(b * p.Hi + iy) * p.Wi + ix) * Csrc + csrc + c4 * 4;
                 }
             }
-            rp[it] = *reinterpret_cast<const float4*>((fromA ? p.src_a : p.src_b) + o);
-            if (!ok) rp[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            rp[it] = *reinterpret_cast<const float4*>(src + o);
+            okp[it] = ok;
         }
-        __syncthreads();   // previous tile's MFMAs are done with LDS
+    };
+    auto store_tile = [&]() {
 #pragma unroll
         for (int it = 0; it < Z_IT; ++it) {
             const int f = tid + it * 256;
-            if (f < Z_F4) *reinterpret_cast<float4*>(&Zs[(f / (COT / 4)) * LDZ + (f % (COT / 4)) * 4]) = rz[it];
+            float4 v = rz[it];
+            if (!okz[it]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (f < Z_F4) *reinterpret_cast<float4*>(&Zs[(f / (COT / 4)) * LDZ + (f % (COT / 4)) * 4]) = v;
         }
 #pragma unroll
         for (int it = 0; it < P_IT; ++it) {
             const int f = tid + it * 256;
-            if (f < P_F4) *reinterpret_cast<float4*>(&Ps[(f / (CIT / 4)) * LDP + (f % (CIT / 4)) * 4]) = rp[it];
+            float4 v = rp[it];
+            if (!okp[it]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (f < P_F4) *reinterpret_cast<float4*>(&Ps[(f / (CIT / 4)) * LDP + (f % (CIT / 4)) * 4]) = v;
         }
+    };
+
+    if (t_beg < t_end) load_tile(t_beg);
+    for (int tile = t_beg; tile < t_end; ++tile) {
+        __syncthreads();   // previous tile's MFMAs are done with LDS
+        store_tile();
         __syncthreads();
+        if (tile + 1 < t_end) load_tile(tile + 1);
         // ---- MFMA: reduction over the BM pixels of the tile, 4 pixels per instruction -----------------
-#pragma unroll 4
-        for (int ks = 0; ks < BM / 4; ++ks) {
+#pragma unroll 2
+        for (int ks = wave; ks < BM / 4; ks += 4) {
             const int pix = ks * 4 + kg;
             const int prow = (pix / TW) * PW + (pix % TW);
             float a[TI];
 #pragma unroll
             for (int i = 0; i < TI; ++i) a[i] = Zs[pix * LDZ + i * 16 + l16];
 #pragma unroll
-            for (int t = 0; t < 3; ++t) {
-                const int tap = wave + 4 * t;
-                if (tap < 9) {
-                    const int off = (tap / 3) * PW + (tap % 3);
+            for (int tap = 0; tap < 9; ++tap) {
+                const int off = (tap / 3) * PW + (tap % 3);
 #pragma unroll
-                    for (int j = 0; j < TJ; ++j) {
-                        const float bv = Ps[(prow + off) * LDP + j * 16 + l16];
+                for (int j = 0; j < TJ; ++j) {
+                    const float bv = Ps[(prow + off) * LDP + j * 16 + l16];
 #pragma unroll
-                        for (int i = 0; i < TI; ++i) acc[t][i][j] = mfma_16x16x4(a[i], bv, acc[t][i][j]);
-                    }
+                    for (int i = 0; i < TI; ++i) acc[tap][i][j] = mfma_16x16x4(a[i], bv, acc[tap][i][j]);
                 }
             }
         }
     }
 
-    // ---- this split's partial: partial[split][co][tap][ci] ---------------------------------------------
+    // ---- sum the four waves' accumulators (fixed order) and write this split's partial:
+    //      partial[split][co][tap][ci] ---------------------------------------------------------------
     float* out = p.partial + (size_t)split * p.Cout * 9 * Cin;
+    float* red = Zs;   // [wave][TI*TJ][lane][4]
 #pragma unroll
-    for (int t = 0; t < 3; ++t) {
-        const int tap = wave + 4 * t;
-        if (tap >= 9) continue;
+    for (int tap = 0; tap < 9; ++tap) {
+        __syncthreads();   // Zs free: MFMAs / previous round done
 #pragma unroll
         for (int i = 0; i < TI; ++i)
 #pragma unroll
             for (int j = 0; j < TJ; ++j)
+                *reinterpret_cast<f32x4*>(&red[((wave * TI * TJ + i * TJ + j) * 64 + lane) * 4]) = acc[tap][i][j];
+        __syncthreads();
+        for (int e = tid; e < TI * TJ * 64; e += 256) {
+            const int ij = e / 64, ln = e % 64;
+            f32x4 s4 = *reinterpret_cast<const f32x4*>(&red[(ij * 64 + ln) * 4]);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int co = co0 + i * 16 + 4 * kg + r;
-                    const int ci = ci0 + j * 16 + l16;
-                    out[((size_t)co * 9 + tap) * Cin + ci] = acc[t][i][j][r];
-                }
+            for (int w = 1; w < 4; ++w) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(&red[((w * TI * TJ + ij) * 64 + ln) * 4]);
+                s4 += v;
+            }
+            const int i = ij / TJ, j = ij % TJ;
+            const int ci = ci0 + j * 16 + (ln & 15);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = co0 + i * 16 + 4 * (ln >> 4) + r;
+                out[((size_t)co * 9 + tap) * Cin + ci] = s4[r];
+            }
+        }
     }
 }
 

@@ -74,7 +74,9 @@ for name, bm, Hi, Wi, Ca, Cb, Cout, k, stride, refl, ups in LAYERS:
             ops.conv_wgrad(desc, dz, part, splits)
             ops.reduce_partials(part, dw, w.numel(), splits)
         t = timeit(f)
-        line += f' | wg{target}(s{splits}):{flops/t/1e12:6.1f}'
+        tk = timeit(lambda: ops.conv_wgrad(desc, dz, part, splits))
+        tr = timeit(lambda: ops.reduce_partials(part, dw, w.numel(), splits))
+        line += f' | wg{target}(s{splits}):{flops/t/1e12:6.1f} [{tk*1e6:.0f}+{tr*1e6:.0f}us]'
     if ops.wgrad_patch_supported(desc):
         for target in (512, 1024, 2048):
             splits = ops.wgrad_patch_splits(desc, target)
@@ -84,5 +86,7 @@ for name, bm, Hi, Wi, Ca, Cb, Cout, k, stride, refl, ups in LAYERS:
                 ops.conv_wgrad_patch(desc, dz, part, splits)
                 ops.reduce_partials(part, dw, w.numel(), splits)
             t = timeit(f2)
-            line += f' | wgP{target}(s{splits}):{flops/t/1e12:6.1f}'
+            tk = timeit(lambda: ops.conv_wgrad_patch(desc, dz, part, splits))
+            tr = timeit(lambda: ops.reduce_partials(part, dw, w.numel(), splits))
+            line += f' | wgP{target}(s{splits}):{flops/t/1e12:6.1f} [{tk*1e6:.0f}+{tr*1e6:.0f}us]'
     print(line, flush=True)
