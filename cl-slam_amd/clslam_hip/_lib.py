@@ -96,7 +96,7 @@ _SIGNATURES = {
     'clslam_se_gate': [fptr, fptr, fptr, fptr, fptr, fptr, i32, i32, i32, C.c_void_p],
     'clslam_channel_scale': [fptr, fptr, i32, i32, i32, C.c_void_p],
     'clslam_adam_step': [fptr, fptr, fptr, fptr, C.c_size_t, C.c_double, C.c_double, C.c_double, C.c_double, i32, C.c_float,
-                         C.c_void_p],
+                         fptr, C.c_void_p],
     'clslam_disp_grad': [fptr, fptr, fptr, i32, fptr, i32, i32, i32, i32, i32, C.c_void_p],
 }
 _RESTYPES = {'clslam_last_error': C.c_char_p}

@@ -287,6 +287,8 @@ class Engine:
         pad_elems = max(B * ((H >> i) + 2) * ((W >> i) + 2) * NUM_CH_DEC[i] for i in range(5))
         t.dxp = [E(pad_elems), E(pad_elems)]
         t.wt = E(256 * 9 * 256)
+        t.wt_ready = None
+        t.wt_dec = {}   # (i, j) -> flipped/transposed upconv_i_j weight for the dgrad convs (refreshed every backward)
         t.dz_p1 = torch.empty_like(ws.p1)
         t.dz_p0 = torch.empty_like(ws.p0)
         t.dz_sq = torch.empty_like(ws.sq)
@@ -516,6 +518,16 @@ class Engine:
         c = ws.ctx
         H, W = self.H, self.W
         feats = ws.dfeats
+        wg = self.wg_stream if (self.use_side_stream and self.wg_stream is not None) else None
+        t.wt_ready = None
+        if wg is None:
+            self._transpose_decoder_weights(t)
+        else:
+            wg.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(wg):
+                self._transpose_decoder_weights(t)
+                t.wt_ready = torch.cuda.Event()
+                t.wt_ready.record(wg)
         # loss -> disparity logits and pose-decoder output ----------------------------------------
         ops.loss_bwd2_pyramid(ws.disp, ws.sel, ws.coef, ws.warped, c.rgb[0], c.rgb[-1], c.rgb[1], c.Kinv, ws.P, c.sample_w,
                               t.ddisp_up, t.dp_partial, self.min_depth, self.max_depth)
@@ -537,6 +549,24 @@ class Engine:
             t.table = ops.make_reduce_table(t.items, self.device)
         ops.reduce_multi(t.table, len(t.items), self.g)
 
+    def _transpose_decoder_weights(self, t) -> None:
+        """Flipped/transposed upconv weights for the dgrad convs.  They depend only on the weights, so all
+        nine are issued at the start of backward() on the wgrad stream, where they overlap the loss
+        backward instead of sitting between the dgrad convs of the critical path."""
+        for i in range(5):
+            ci = NUM_CH_DEC[i]
+            cin1 = ci + (NUM_CH_ENC[i - 1] if i > 0 else 0)
+            if (i, 1) not in t.wt_dec:
+                t.wt_dec[i, 1] = torch.empty(ci, 9, ci, device=self.device)
+            w1, _ = self._wb(f'depth_decoder/upconv_{i}_1.conv.conv', ci, cin1, 9)
+            ops.weight_transpose(w1, t.wt_dec[i, 1], ch_in_sel=ci)   # only the up(x[i,0]) half: the skip half is frozen
+            if i < 4:
+                cin0 = NUM_CH_DEC[i + 1]
+                if (i, 0) not in t.wt_dec:
+                    t.wt_dec[i, 0] = torch.empty(cin0, 9, ci, device=self.device)
+                w0, _ = self._wb(f'depth_decoder/upconv_{i}_0.conv.conv', ci, cin0, 9)
+                ops.weight_transpose(w0, t.wt_dec[i, 0])
+
     def _backward_depth_decoder(self, ws, t, B: int) -> None:
         """dgrad chain (critical path) on the current stream; every weight/bias gradient is independent
         of the rest of the chain once its dz exists, so those run on a third stream (`wg_stream`)."""
@@ -557,6 +587,9 @@ class Engine:
             wg.wait_event(ev)
             with torch.cuda.stream(wg):
                 fn()
+
+        if t.wt_ready is not None:
+            main.wait_event(t.wt_ready)     # transposed dgrad weights (issued at the start of backward())
 
         dxp_in = None  # padded-domain gradient w.r.t. x[i,1] coming from upconv_{i-1}_0
         for i in range(5):
@@ -586,9 +619,7 @@ class Engine:
             on_wg(lambda i=i, hi=hi, wi=wi, ci=ci, skip=skip, cin1=cin1, nb1=nb1: self._wgrad(
                 t, (ws.x[i, 0], skip), (B, hi, wi, ci), t.dz[i, 1], f'depth_decoder/upconv_{i}_1.conv.conv', ci, cin1, 9,
                 bias_blocks=nb1, bias_partial=t.bias_part[i, 1], pad_mode=PAD_REFLECT, upsample_a=True))
-            w1, _ = self._wb(f'depth_decoder/upconv_{i}_1.conv.conv', ci, cin1, 9)
-            wt = t.wt[:ci * 9 * ci].view(ci, 9, ci)
-            ops.weight_transpose(w1, wt, ch_in_sel=ci)          # only the up(x[i,0]) half: the skip half is frozen
+            wt = t.wt_dec[i, 1]
             dxa = t.dxp[1][:B * (hi + 2) * (wi + 2) * ci].view(B, hi + 2, wi + 2, ci)
             ops.conv2d(t.dz[i, 1], wt, dxa, ksize=3, pad=2)
             nb0 = ops.fold_blocks(B, hi, wi, ci, True)
@@ -602,9 +633,7 @@ class Engine:
                 t, (src, None), (B, h2, w2, ci), t.dz[i, 0], f'depth_decoder/upconv_{i}_0.conv.conv', ci, cin0, 9,
                 bias_blocks=nb0, bias_partial=t.bias_part[i, 0], pad_mode=PAD_REFLECT))
             if i < 4:
-                w0, _ = self._wb(f'depth_decoder/upconv_{i}_0.conv.conv', ci, cin0, 9)
-                wt = t.wt[:cin0 * 9 * ci].view(cin0, 9, ci)
-                ops.weight_transpose(w0, wt)
+                wt = t.wt_dec[i, 0]
                 dxp_in = t.dxp[0][:B * (h2 + 2) * (w2 + 2) * cin0].view(B, h2 + 2, w2 + 2, cin0)
                 ops.conv2d(t.dz[i, 0], wt, dxp_in, ksize=3, pad=2)
         if wg is not None:
@@ -700,9 +729,10 @@ class Engine:
         return outputs, st.losses.clone()
 
     # ------------------------------------------------------------------------------------------
-    def adam(self, lr: float, betas=(0.9, 0.999), eps: float = 1e-8) -> None:
+    def adam(self, lr: float, betas=(0.9, 0.999), eps: float = 1e-8, guard: Optional[torch.Tensor] = None) -> None:
+        """guard: the step's loss (1 element); a NaN there makes the kernel skip the update."""
         self.adam_step_count += 1
-        ops.adam_step(self.w, self.g, self.m, self.v, lr, self.adam_step_count, betas[0], betas[1], eps)
+        ops.adam_step(self.w, self.g, self.m, self.v, lr, self.adam_step_count, betas[0], betas[1], eps, guard=guard)
         self._modules_stale = True
 
     # ------------------------------------------------------------------------------------------

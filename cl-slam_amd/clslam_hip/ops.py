@@ -284,9 +284,10 @@ def disp_grad(ddisp_up, disp, smooth_aux, n_smooth, dz, H, W):
                         _stream(dz))
 
 
-def adam_step(param, grad, exp_avg, exp_avg_sq, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
+def adam_step(param, grad, exp_avg, exp_avg_sq, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0, guard=None):
+    """guard: optional 1-element fp32 tensor (the step's loss); NaN there turns the launch into a no-op."""
     _lib.get_lib().call('clslam_adam_step', _p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(), lr, beta1,
-                        beta2, eps, step, grad_scale, _stream(param))
+                        beta2, eps, step, grad_scale, _p(guard), _stream(param))
 
 
 # ---- loop-closure encoder (MobileNetV3-small) ops ------------------------------------------------

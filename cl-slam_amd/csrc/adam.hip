@@ -10,7 +10,11 @@ namespace clslam {
 
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, size_t n4, size_t n, float step_size, float w1,
-                                                   float beta2, float w2, float bc2_sqrt, float eps, float grad_scale) {
+                                                   float beta2, float w2, float bc2_sqrt, float eps, float grad_scale,
+                                                   const float* __restrict__ guard) {
+    // guard (optional): the step's total loss.  NaN -> no update at all (dpp.py:1115-1118 raises before
+    // backward/step; the host raises after this launch, see DepthPosePrediction.adapt).
+    if (guard && !(guard[0] == guard[0])) return;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
         float4 pp = reinterpret_cast<float4*>(p)[i];
         float4 gg = reinterpret_cast<const float4*>(g)[i];
@@ -46,7 +50,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 using namespace clslam;
 
 extern "C" int clslam_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, double lr,
-                                double beta1, double beta2, double eps, int step, float grad_scale, void* stream) {
+                                double beta1, double beta2, double eps, int step, float grad_scale, const float* guard, void* stream) {
     CLSLAM_REQUIRE(param && grad && exp_avg && exp_avg_sq && step >= 1, "adam_step: bad args");
     if (!n) return CLSLAM_OK;
     // scalars are formed in double like torch's python-side arithmetic, then rounded to fp32 once
@@ -57,6 +61,6 @@ extern "C" int clslam_adam_step(float* param, const float* grad, float* exp_avg,
     const size_t n4 = n / 4;
     const unsigned blocks = (unsigned)std::min<size_t>(2048, std::max<size_t>(1, (n4 + 255) / 256));
     hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n4, n,
-                       step_size, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), bc2_sqrt, (float)eps, grad_scale);
+                       step_size, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), bc2_sqrt, (float)eps, grad_scale, guard);
     return check_launch("adam_step");
 }

@@ -41,12 +41,15 @@ __global__ __launch_bounds__(256) void fold_act_grad_kernel(const float* __restr
     const int Ho = pool ? H / 2 : H, Wo = pool ? W / 2 : W;
     const int C4 = C / 4;
     const int Hp = H + 2 * e, Wp = W + 2 * e;
-    const size_t total = (size_t)B * Ho * Wo * C4;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int c4 = (int)(i % C4);
-        const int x = (int)((i / C4) % Wo);
-        const int y = (int)((i / ((size_t)C4 * Wo)) % Ho);
-        const int b = (int)(i / ((size_t)C4 * Wo * Ho));
+    // 32-bit index arithmetic (the host checks total < 2^31): 64-bit div/mod chains cost more than the loads
+    const int total = B * Ho * Wo * C4;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int c4 = i % C4;
+        const int pix = i / C4;
+        const int x = pix % Wo;
+        const int row = pix / Wo;
+        const int y = row % Ho;
+        const int b = row / Ho;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         const int ny = pool ? 2 : 1;
         for (int dy = 0; dy < ny; ++dy) {
@@ -379,6 +382,7 @@ extern "C" int clslam_fold_act_grad(const float* dxp, const float* yout, float* 
     const size_t total = (size_t)batch * (pool ? h / 2 : h) * (pool ? w / 2 : w) * (ch / 4);
     if (total == 0) return CLSLAM_OK;
     CLSLAM_REQUIRE(!bias_partial || (256 % (ch / 4) == 0), "fold_act_grad: fused bias sums need ch/4 to divide 256");
+    CLSLAM_REQUIRE(total < ((size_t)1 << 31) - 256 * 4096, "fold_act_grad: tensor too large for 32-bit indexing");
     const int blocks = clslam_fold_blocks(batch, h, w, ch, pool);
     hipLaunchKernelGGL(fold_act_grad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dxp, yout, dz, bias_partial, batch,
                        h, w, ch, border, pool, act, ch_stride);

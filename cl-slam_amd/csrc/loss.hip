@@ -18,6 +18,7 @@ __device__ __forceinline__ int refl(int i, int n) { return reflect_idx(i, n); }
 
 // SSIM+L1 map value of one pixel for one (pred, target) image pair; optionally the 9 derivative
 // coefficients (alpha, beta, gamma per channel) described at photo_map_kernel.
+template <bool COEF>
 __device__ __forceinline__ float photo_px(const float* __restrict__ pred_n, const float* __restrict__ target_b, int H, int W,
                                           int y, int x, float* coef9) {
     const float C1 = 0.0001f, C2 = 0.0009f;
@@ -43,7 +44,7 @@ __device__ __forceinline__ float photo_px(const float* __restrict__ pred_n, cons
         const float raw = (1.f - S) / 2.f;
         ssim_sum += fminf(fmaxf(raw, 0.f), 1.f);
         l1_sum += fabsf(tp[y * W + x] - pp[y * W + x]);
-        if (coef9) {
+        if constexpr (COEF) {
             const float kf = (raw >= 0.f && raw <= 1.f) ? (0.85f / 3.f) * (-0.5f) / 9.f : 0.f;
             coef9[c * 3 + 0] = kf * ((2.f * mu_y * (n2 - n1)) / d - S * (2.f * mu_x * (d2 - d1)) / d);
             coef9[c * 3 + 1] = kf * (-2.f * S * d1 / d);
@@ -57,6 +58,7 @@ __device__ __forceinline__ float photo_px(const float* __restrict__ pred_n, cons
 // both reprojection maps of a pixel are evaluated in registers, the 4-way min / argmin is taken against
 // the (scale-independent) identity maps + noise, and ONLY the selected frame's 9 SSIM coefficients are
 // stored (coef_sel (S,B,9,H,W)); no reprojection maps, no per-frame coefficient planes in HBM.
+template <bool TRAIN>   // TRAIN: coef_sel_all != nullptr (a runtime pointer select would push k2/k3 to scratch)
 __global__ __launch_bounds__(256) void photo_automask_kernel(const float* __restrict__ warped_all, const float* __restrict__ target,
                                                              const float* __restrict__ idmap, const float* __restrict__ noise_all,
                                                              unsigned char* __restrict__ sel_all, float* __restrict__ coef_sel_all,
@@ -77,16 +79,18 @@ __global__ __launch_bounds__(256) void photo_automask_kernel(const float* __rest
         float c1 = idmap[((size_t)1 * B + b) * HW + p];
         if (noise) { c0 += noise[((size_t)b * 2 + 0) * HW + p]; c1 += noise[((size_t)b * 2 + 1) * HW + p]; }
         float k2[9], k3[9];
-        const float c2 = photo_px(warped + ((size_t)0 * B + b) * 3 * HW, target + (size_t)b * 3 * HW, H, W, y, x, coef_sel ? k2 : nullptr);
-        const float c3 = photo_px(warped + ((size_t)1 * B + b) * 3 * HW, target + (size_t)b * 3 * HW, H, W, y, x, coef_sel ? k3 : nullptr);
+        const float c2 = photo_px<TRAIN>(warped + ((size_t)0 * B + b) * 3 * HW, target + (size_t)b * 3 * HW, H, W, y, x, k2);
+        const float c3 = photo_px<TRAIN>(warped + ((size_t)1 * B + b) * 3 * HW, target + (size_t)b * 3 * HW, H, W, y, x, k3);
         float m = c0; int k = 0;
         if (c1 < m) { m = c1; k = 1; }
         if (c2 < m) { m = c2; k = 2; }
         if (c3 < m) { m = c3; k = 3; }
         sel[p] = (unsigned char)k;
-        if (coef_sel && k >= 2) {
+        if constexpr (TRAIN) {
+            if (k >= 2) {
 #pragma unroll
-            for (int q = 0; q < 9; ++q) coef_sel[(size_t)q * HW + p] = (k == 2) ? k2[q] : k3[q];
+                for (int q = 0; q < 9; ++q) coef_sel[(size_t)q * HW + p] = (k == 2) ? k2[q] : k3[q];
+            }
         }
         s += m;
     }
@@ -737,8 +741,12 @@ extern "C" int clslam_photo_automask_pyramid(const float* warped, const float* t
     CLSLAM_REQUIRE(warped && target && idmap && sel && partial && H >= 2 && W >= 2, "photo_automask_pyramid: bad args");
     if (!batch) return CLSLAM_OK;
     const int nblk = clslam_automask_blocks(H, W);
-    hipLaunchKernelGGL(photo_automask_kernel, dim3(nblk, batch, 4), dim3(256), 0, (hipStream_t)stream, warped, target, idmap, noise,
-                       sel, coef_sel, partial, batch, H, W, cdiv(H * W, nblk));
+    if (coef_sel)
+        hipLaunchKernelGGL(photo_automask_kernel<true>, dim3(nblk, batch, 4), dim3(256), 0, (hipStream_t)stream, warped, target,
+                           idmap, noise, sel, coef_sel, partial, batch, H, W, cdiv(H * W, nblk));
+    else
+        hipLaunchKernelGGL(photo_automask_kernel<false>, dim3(nblk, batch, 4), dim3(256), 0, (hipStream_t)stream, warped, target,
+                           idmap, noise, sel, coef_sel, partial, batch, H, W, cdiv(H * W, nblk));
     return check_launch("photo_automask_pyramid");
 }
 

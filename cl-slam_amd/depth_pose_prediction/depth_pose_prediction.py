@@ -41,6 +41,7 @@ class EngineAdam(optim.Adam):
         super().__init__(params, lr)
         self._engine = engine
         self._names = names  # 'model/key' per param index
+        self.loss_guard = None  # 1-element loss tensor of the step in flight: NaN -> the kernel skips the update
 
     def zero_grad(self, set_to_none: bool = True) -> None:  # gradients are overwritten, never accumulated
         return None
@@ -48,7 +49,7 @@ class EngineAdam(optim.Adam):
     @torch.no_grad()
     def step(self, closure=None):
         g = self.param_groups[0]
-        self._engine.adam(g['lr'], g['betas'], g['eps'])
+        self._engine.adam(g['lr'], g['betas'], g['eps'], guard=self.loss_guard)
 
     def state_dict(self):
         sd = super().state_dict()
@@ -215,6 +216,8 @@ class DepthPosePrediction:
 
         self._dp = None
         self._injected_noise = None
+        self._loss_host = None   # pinned 1-float staging buffer + event for the per-step NaN check
+        self._loss_event = None
         self._mode = None
 
     # ============================================================
@@ -273,7 +276,16 @@ class DepthPosePrediction:
                     outputs_eval, losses = self._process_batch(training_data, loss_weights, train=True)
                     self.optimizer.zero_grad()
                     self._backward(training_data)
+                # dpp.py:1115-1118 aborts on a NaN loss before backward/step.  Checking there costs a full host
+                # sync in the middle of the step (the GPU idles while the host enqueues the backward), and a
+                # sync at the end of the step starves the GPU at the start of the next one.  Instead the
+                # forward copies the loss to pinned host memory behind an event; backward and a device-
+                # guarded Adam (no-op when the loss is NaN) are enqueued, and only then does the host wait
+                # for THAT event -- the GPU still has the whole backward queued while the host goes on.
+                self.optimizer.loss_guard = losses['loss']
                 self.optimizer.step()
+                self.optimizer.loss_guard = None
+                self._raise_on_nan(losses, undo_step=True, staged=True)
         else:
             self._set_eval()
             self.engine.pack_if_needed()
@@ -445,11 +457,30 @@ class DepthPosePrediction:
         if self._dp is not None:
             self._dp['dist'].all_reduce(losses, group=self._dp['group'])
         loss_dict = self.engine.losses_dict(losses)
-        if np.isnan(loss_dict['loss'].item()):  # dpp.py:1115-1118 (also the step's only host sync)
+        if not train:
+            self._raise_on_nan(loss_dict)
+        elif self.device.type == 'cuda':   # training steps check after the optimizer launch (see adapt)
+            if self._loss_host is None:
+                self._loss_host = torch.empty(1, dtype=torch.float32, pin_memory=True)
+                self._loss_event = torch.cuda.Event()
+            self._loss_host.copy_(loss_dict['loss'], non_blocking=True)
+            self._loss_event.record()
+        return outputs, loss_dict
+
+    def _raise_on_nan(self, loss_dict, undo_step: bool = False, staged: bool = False) -> None:
+        """dpp.py:1115-1118 (the step's only host wait).  staged: the loss was copied to pinned memory by
+        the forward; wait for that copy only, not for the stream."""
+        if staged and self.device.type == 'cuda':
+            self._loss_event.synchronize()
+            value = float(self._loss_host[0])
+        else:
+            value = loss_dict['loss'].item()
+        if np.isnan(value):
+            if undo_step:   # the guarded Adam launch did not touch weights or moments
+                self.engine.adam_step_count -= 1
             for k, v in loss_dict.items():
                 print(k, v.item())
             raise RuntimeError('NaN loss')
-        return outputs, loss_dict
 
     def _backward(self, inputs: Dict[Any, Tensor]) -> None:
         B = inputs['rgb_aug', 0, 0].shape[0]

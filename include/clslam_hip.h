@@ -240,9 +240,12 @@ int clslam_disp_grad(const float* ddisp_up, const float* disp, const float* smoo
 /* ---------------------------------------------------------------------------------------------
  * Fused Adam over a flat fp32 arena.  Replaces torch.optim.Adam.step() (dpp.py:203,313; torch
  * defaults, same op order as the single-tensor CPU implementation).  grad is multiplied by
- * grad_scale first (1 for single GPU; data-parallel ranks all-reduce with SUM, so it stays 1).  */
+ * grad_scale first (1 for single GPU; data-parallel ranks all-reduce with SUM, so it stays 1).
+ * guard (device pointer or NULL): when *guard is NaN the launch leaves param and both moments
+ * untouched -- the NaN-loss abort of dpp.py:1115-1118 without a host sync between forward and
+ * backward (the host checks the loss once per step, after the optimizer launch).               */
 int clslam_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, double lr,
-                     double beta1, double beta2, double eps, int step, float grad_scale, void* stream);
+                     double beta1, double beta2, double eps, int step, float grad_scale, const float* guard, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Loop-closure feature encoder: MobileNetV3-small forward (loop_closure_detection/encoder.py:13-33:

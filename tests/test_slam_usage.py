@@ -87,3 +87,28 @@ def test_api_corners_match_oracle(backend):
     assert set(pred.keys()) == set(oo.keys())
     with pytest.raises(RuntimeError):   # actual batch neither 1 nor batch_size
         p.adapt(None, synth.make_batch(3, H, W, seed=1), steps=1)
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_nan_loss_aborts_without_update(backend):
+    """dpp.py:1115-1118: a NaN loss raises RuntimeError('NaN loss') and the optimizer step does not
+    happen.  The product checks once per step, after the (device-guarded) Adam launch: weights,
+    moments and the step count must be exactly what they were."""
+    use_backend(backend)
+    B = 2
+    p = make_predictor(H, W, B)
+    batch = synth.make_batch(B, H, W, seed=5)
+    p.adapt(None, {k: v.clone() for k, v in batch.items()}, steps=1)      # one good step: moments non-zero
+    w0, m0, v0 = p.engine.w.clone(), p.engine.m.clone(), p.engine.v.clone()
+    count0 = p.engine.adam_step_count
+    bad = {k: v.clone() for k, v in batch.items()}
+    bad['relative_distance', 0] = torch.full_like(bad['relative_distance', 0], float('nan'))   # velocity loss -> NaN
+    with pytest.raises(RuntimeError, match='NaN loss'):
+        p.adapt(None, bad, steps=1)
+    assert torch.equal(p.engine.w, w0) and torch.equal(p.engine.m, m0) and torch.equal(p.engine.v, v0)
+    assert p.engine.adam_step_count == count0
+    with pytest.raises(RuntimeError, match='NaN loss'):                     # eval path: immediate check
+        p.adapt({k: v.clone() for k, v in bad.items()}, None)
+    p.adapt(None, {k: v.clone() for k, v in batch.items()}, steps=1)      # and the predictor is still usable
+    assert p.engine.adam_step_count == count0 + 1
+    assert not torch.equal(p.engine.w, w0)
