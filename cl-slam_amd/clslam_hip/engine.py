@@ -371,8 +371,33 @@ class Engine:
             ws.disp = [E(B, H >> s, W >> s) for s in range(4)]
             ws.pose, ws.T = E(2 * B, 12), E(2, B, 4, 4)
             ws.depth, ws.warped, ws.losses = E(4, B, H, W), E(4, 2, B, 3, H, W), E(18)
+        def identity_and_noise() -> bool:
+            """Identity reprojection maps (dpp.py:1047-1052) and the tie-break noise depend on the inputs only."""
+            ws.idsrc[0].copy_(rgb[-1])
+            ws.idsrc[1].copy_(rgb[1])
+            ops.photo_map(ws.idsrc, rgb[0], ws.idmap, None, 2 * B, B, H, W)
+            if noise is not None:
+                for s in range(4):
+                    ws.noise[s].copy_(noise[s])
+                return True
+            if keep_noise:                       # already copied into ws.noise by the graph driver
+                return True
+            if draw_noise:
+                ws.noise.normal_().mul_(1e-5)  # dpp.py:1055-1056
+                return True
+            return False
+
         # networks ---------------------------------------------------------------------------
         side = self.side_stream if (self.use_side_stream and self.side_stream is not None) else None
+        id_ready = None
+        wg = self.wg_stream if (self.use_side_stream and self.wg_stream is not None) else None
+        if wg is not None:
+            # the wgrad stream idles during the forward: the input-only work runs there, off the critical path
+            wg.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(wg):
+                have_noise = identity_and_noise()
+                id_ready = torch.cuda.Event()
+                id_ready.record(wg)
         if side is not None:
             main = torch.cuda.current_stream(self.device)
             side.wait_stream(main)
@@ -406,20 +431,10 @@ class Engine:
         Kinv = self._mat(inputs['inv_camera_matrix', 0])
         ops.pose_to_proj(ws.pose, K, ws.T, ws.P)
         ops.warp_fwd_pyramid(ws.disp, rgb[-1], rgb[1], Kinv, ws.P, ws.depth, ws.warped, self.min_depth, self.max_depth)
-        ws.idsrc[0].copy_(rgb[-1])
-        ws.idsrc[1].copy_(rgb[1])
-        ops.photo_map(ws.idsrc, rgb[0], ws.idmap, None, 2 * B, B, H, W)
-        if noise is not None:
-            for s in range(4):
-                ws.noise[s].copy_(noise[s])
-            have_noise = True
-        elif keep_noise:                       # already copied into ws.noise by the graph driver
-            have_noise = True
-        elif draw_noise:
-            ws.noise.normal_().mul_(1e-5)  # dpp.py:1055-1056
-            have_noise = True
+        if id_ready is not None:
+            torch.cuda.current_stream(self.device).wait_event(id_ready)
         else:
-            have_noise = False
+            have_noise = identity_and_noise()
         # all four scales in one launch; reprojection maps stay in registers, only the selected frame's
         # SSIM coefficients are kept for the backward
         ops.photo_automask_pyramid(ws.warped, rgb[0], ws.idmap, ws.noise if have_noise else None, ws.sel,

@@ -666,6 +666,73 @@ __global__ __launch_bounds__(256) void disp_grad_kernel(const float* ddisp_up, c
     }
 }
 
+// Pyramid form of disp_grad_kernel, lane-cooperative.  The bilinear footprint of low-res pixel (i,j) at
+// factor f = H/h in {1,2,4,8} is the 2f x 2f window starting at (f*i - f/2, f*j - f/2); a one-thread-per-
+// output loop over it is a long serial chain of dependent loads at the coarse scales (measured 96 us).
+// Here f*f lanes share one output pixel (4 taps each: (qy, qx) + {0,f} in both axes; consecutive lanes
+// read consecutive X), then xor-shuffle reduce: every scale exposes B*H*W threads of equal work.
+__global__ __launch_bounds__(256) void disp_grad_coop_kernel(const float* __restrict__ ddisp_up_all, const float* __restrict__ smooth_all,
+                                                             int n_smooth, int B, int H, int W, Pyramid pyr, DzPtrs dzp) {
+    const int sc = blockIdx.y;
+    const int h = pyr.h[sc], w = pyr.w[sc];
+    const int f = H / h, G = f * f;
+    const float* __restrict__ disp = pyr.disp[sc];
+    float* __restrict__ dz = dzp.dz[sc];
+    const float* __restrict__ ddisp_up = ddisp_up_all + (size_t)sc * B * H * W;
+    const float* smooth_aux = smooth_all ? smooth_all + (size_t)sc * (2 + 2 * n_smooth) : nullptr;
+    const float ry = (float)h / (float)H, rx = (float)w / (float)W;
+    const int total = B * H * W;                       // = outputs * G
+    const int t = blockIdx.x * 256 + threadIdx.x;      // grid covers total exactly up to the last block
+    const bool live = t < total;
+    const int idx = live ? t / G : 0, q = t % G;
+    const int qy = q / f, qx = q % f;
+    const int j = idx % w, i = (idx / w) % h, b = idx / (w * h);
+    float g = 0.f;
+    if (live) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int Y = f * i - f / 2 + qy + a * f;
+            if (Y < 0 || Y >= H) continue;
+            float sy = ry * ((float)Y + 0.5f) - 0.5f; if (sy < 0.f) sy = 0.f;
+            const int y0 = (int)sy, y1 = y0 + (y0 < h - 1 ? 1 : 0);
+            const float ly = sy - (float)y0;
+            float wy = 0.f;
+            if (y0 == i) wy += 1.f - ly;
+            if (y1 == i) wy += ly;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int X = f * j - f / 2 + qx + c * f;
+                if (X < 0 || X >= W) continue;
+                float sx = rx * ((float)X + 0.5f) - 0.5f; if (sx < 0.f) sx = 0.f;
+                const int x0 = (int)sx, x1 = x0 + (x0 < w - 1 ? 1 : 0);
+                const float lx = sx - (float)x0;
+                float wx = 0.f;
+                if (x0 == j) wx += 1.f - lx;
+                if (x1 == j) wx += lx;
+                g += wy * wx * ddisp_up[((size_t)b * H + Y) * W + X];
+            }
+        }
+    }
+    for (int m = 1; m < G; m <<= 1) g += wave_shfl_xor(g, m);   // G <= 64 lanes of one wave, aligned
+    if (live && q == 0) {
+        if (n_smooth > 0 && b == 0) {
+            const float inv0 = smooth_aux[0], fb = smooth_aux[1];
+            const float* gxs = smooth_aux + 2;
+            const float* gys = smooth_aux + 2 + n_smooth;
+            float D = 0.f;
+            if (i == 0) {
+                if (j < n_smooth) D += gxs[j] + gys[j];
+                if (j >= 1 && j - 1 < n_smooth) D -= gxs[j - 1];
+            } else if (i == 1) {
+                if (j < n_smooth) D -= gys[j];
+            }
+            g += inv0 * D - fb;
+        }
+        const float d = disp[idx];
+        dz[idx] = g * d * (1.f - d);
+    }
+}
+
 }  // namespace clslam
 
 using namespace clslam;
@@ -834,7 +901,8 @@ extern "C" int clslam_disp_grad_pyramid(const float* ddisp_up, const float* cons
     CLSLAM_REQUIRE(n_smooth == 0 || (smooth_aux && n_smooth < (W >> 3) - 1 && (H >> 3) >= 2), "disp_grad_pyramid: smoothness layout unsupported");
     if (!batch) return CLSLAM_OK;
     DzPtrs dzp; for (int k = 0; k < 4; ++k) dzp.dz[k] = dz[k];
-    hipLaunchKernelGGL(disp_grad_kernel, dim3(grid1d((size_t)batch * H * W), 4), dim3(256), 0, (hipStream_t)stream, ddisp_up,
-                       (const float*)nullptr, smooth_aux, n_smooth, (float*)nullptr, batch, 0, 0, H, W, make_pyramid(disp, H, W), dzp);
+    CLSLAM_REQUIRE(H % 8 == 0 && W % 8 == 0 && (size_t)batch * H * W < ((size_t)1 << 31), "disp_grad_pyramid: H, W must be multiples of 8");
+    hipLaunchKernelGGL(disp_grad_coop_kernel, dim3(cdiv(batch * H * W, 256), 4), dim3(256), 0, (hipStream_t)stream, ddisp_up,
+                       smooth_aux, n_smooth, batch, H, W, make_pyramid(disp, H, W), dzp);
     return check_launch("disp_grad_pyramid");
 }
