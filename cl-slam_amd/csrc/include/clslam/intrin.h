@@ -25,12 +25,29 @@ __device__ __forceinline__ f32x4 mfma_16x16x4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-// butterfly all-reduce over the 64 lanes (deterministic pairing order)
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+// DPP lane permutation inside a 16-lane row (quad_perm / row_mirror / row_half_mirror controls)
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
 }
+
+// Sum over the 64 lanes, returned in every lane; call from wave-uniform control flow only.  Four DPP
+// adds (VALU, no LDS traffic -- __shfl_xor is a ds_bpermute per step) leave every lane with the sum of
+// its 16-lane row, the four row sums are read with v_readlane and added on the scalar side.  Fixed
+// pairing order: deterministic.
+__device__ __forceinline__ float wave_sum(float v) {
+    v += dpp_mov<0xB1>(v);    // quad_perm:[1,0,3,2]
+    v += dpp_mov<0x4E>(v);    // quad_perm:[2,3,0,1]
+    v += dpp_mov<0x141>(v);   // row_half_mirror
+    v += dpp_mov<0x140>(v);   // row_mirror
+    const int iv = __builtin_bit_cast(int, v);
+    return (__builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 16))) +
+           (__builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 48)));
+}
+
+// 1/x to 1 ulp (v_rcp_f32) -- for the SSIM / projection quotients of the loss kernels, where an IEEE
+// division costs ~10 instructions and the last ulp is far below the 1e-4 parity bar
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
 // value of lane (lane ^ mask)
 __device__ __forceinline__ float wave_shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }

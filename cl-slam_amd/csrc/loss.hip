@@ -16,71 +16,111 @@ namespace clslam {
 
 __device__ __forceinline__ int refl(int i, int n) { return reflect_idx(i, n); }
 
-// SSIM+L1 map value of one pixel for one (pred, target) image pair; optionally the 9 derivative
-// coefficients (alpha, beta, gamma per channel) described at photo_map_kernel.
-template <bool COEF>
-__device__ __forceinline__ float photo_px(const float* __restrict__ pred_n, const float* __restrict__ target_b, int H, int W,
-                                          int y, int x, float* coef9) {
-    const float C1 = 0.0001f, C2 = 0.0009f;
-    const size_t HW = (size_t)H * W;
-    int ys[3], xs[3];
-    for (int k = 0; k < 3; ++k) { ys[k] = refl(y + k - 1, H); xs[k] = refl(x + k - 1, W); }
-    float ssim_sum = 0.f, l1_sum = 0.f;
-    for (int c = 0; c < 3; ++c) {
-        const float* pp = pred_n + (size_t)c * HW;
-        const float* tp = target_b + (size_t)c * HW;
-        float sx = 0.f, sy = 0.f, sxx = 0.f, syy = 0.f, sxy = 0.f;
-        for (int ky = 0; ky < 3; ++ky)
-            for (int kx = 0; kx < 3; ++kx) {
-                const float xv = pp[ys[ky] * W + xs[kx]], yv = tp[ys[ky] * W + xs[kx]];
-                sx += xv; sy += yv; sxx += xv * xv; syy += yv * yv; sxy += xv * yv;
-            }
-        const float mu_x = sx / 9.f, mu_y = sy / 9.f;
-        const float sig_x = sxx / 9.f - mu_x * mu_x, sig_y = syy / 9.f - mu_y * mu_y, sig_xy = sxy / 9.f - mu_x * mu_y;
-        const float n1 = 2.f * mu_x * mu_y + C1, n2 = 2.f * sig_xy + C2;
-        const float d1 = mu_x * mu_x + mu_y * mu_y + C1, d2 = sig_x + sig_y + C2;
-        const float d = d1 * d2;
-        const float S = (n1 * n2) / d;
-        const float raw = (1.f - S) / 2.f;
-        ssim_sum += fminf(fmaxf(raw, 0.f), 1.f);
-        l1_sum += fabsf(tp[y * W + x] - pp[y * W + x]);
-        if constexpr (COEF) {
-            const float kf = (raw >= 0.f && raw <= 1.f) ? (0.85f / 3.f) * (-0.5f) / 9.f : 0.f;
-            coef9[c * 3 + 0] = kf * ((2.f * mu_y * (n2 - n1)) / d - S * (2.f * mu_x * (d2 - d1)) / d);
-            coef9[c * 3 + 1] = kf * (-2.f * S * d1 / d);
-            coef9[c * 3 + 2] = kf * (2.f * n1 / d);
-        }
-    }
-    return 0.85f * (ssim_sum / 3.f) + 0.15f * (l1_sum / 3.f);
+// x / 9 correctly rounded in 3 instructions (Markstein: q = RN(x * r), q' = RN(q + RN(x - 9q) * r) with
+// r = RN(1/9)) instead of the ~10 of an IEEE division.  The 3x3 window means feed sigma = E[x^2] - mu^2, a
+// cancellation that amplifies a 1-ulp difference in the means to ~1e-5 in the SSIM value -- enough to flip
+// near-ties of the 4-way min against the reference, so the quotient has to be the exact one.
+__device__ __forceinline__ float div9(float x) {
+    const float r = 1.f / 9.f;
+    const float q = x * r;
+    return fmaf(fmaf(-9.f, q, x), r, q);
 }
 
 // Fused photometric map + auto-masking for the whole pyramid (one launch, grid (nblk, B, nscale)):
 // both reprojection maps of a pixel are evaluated in registers, the 4-way min / argmin is taken against
 // the (scale-independent) identity maps + noise, and ONLY the selected frame's 9 SSIM coefficients are
 // stored (coef_sel (S,B,9,H,W)); no reprojection maps, no per-frame coefficient planes in HBM.
-template <bool TRAIN>   // TRAIN: coef_sel_all != nullptr (a runtime pointer select would push k2/k3 to scratch)
+constexpr int PA_TH = 8, PA_TW = 64, PA_PH = PA_TH + 2, PA_PW = PA_TW + 2;
+
+// LDS-tiled: a block owns an 8 x 64 pixel tile of one (scale, sample).  The target tile and both warped
+// tiles (3 channels each, 1-pixel halo with the reflection padding of the SSIM blocks resolved while
+// staging) are read from HBM once (x1.29 halo) instead of 9x through L1 per window; the 3x3 statistics
+// then come from LDS.  TRAIN: coef_sel_all != nullptr (a runtime pointer select would push the
+// coefficient arrays to scratch).
+template <bool TRAIN>
 __global__ __launch_bounds__(256) void photo_automask_kernel(const float* __restrict__ warped_all, const float* __restrict__ target,
                                                              const float* __restrict__ idmap, const float* __restrict__ noise_all,
                                                              unsigned char* __restrict__ sel_all, float* __restrict__ coef_sel_all,
-                                                             float* __restrict__ partial_all, int B, int H, int W,
-                                                             int pix_per_block) {
+                                                             float* __restrict__ partial_all, int B, int H, int W, int tilesX) {
+    __shared__ float tl[9][PA_PH * PA_PW];   // planes 0-2: target, 3-5: warped frame 0, 6-8: warped frame 1
     __shared__ float red[4];
+    const float C1 = 0.0001f, C2 = 0.0009f;
     const int b = blockIdx.y, sc = blockIdx.z;
     const int HW = H * W;
+    const int ty = blockIdx.x / tilesX, tx = blockIdx.x - ty * tilesX;
+    const int y0 = ty * PA_TH, x0 = tx * PA_TW;
     const float* warped = warped_all + (size_t)sc * 2 * B * 3 * HW;
     const float* noise = noise_all ? noise_all + (size_t)sc * B * 2 * HW : nullptr;
     unsigned char* sel = sel_all + ((size_t)sc * B + b) * HW;
-    float* coef_sel = coef_sel_all ? coef_sel_all + ((size_t)sc * B + b) * 9 * HW : nullptr;
-    const int p0 = blockIdx.x * pix_per_block, p1 = min(HW, p0 + pix_per_block);
+    float* coef_sel = TRAIN ? coef_sel_all + ((size_t)sc * B + b) * 9 * HW : nullptr;
+    const float* tgt = target + (size_t)b * 3 * HW;
+    const float* wp0 = warped + ((size_t)0 * B + b) * 3 * HW;
+    const float* wp1 = warped + ((size_t)1 * B + b) * 3 * HW;
+    for (int e = threadIdx.x; e < PA_PH * PA_PW; e += 256) {
+        const int r = e / PA_PW, c = e - r * PA_PW;
+        // reflection padding; tiles overhanging the image clamp (those pixels are never consumed)
+        const int yy = min(max(refl(y0 - 1 + r, H), 0), H - 1), xx = min(max(refl(x0 - 1 + c, W), 0), W - 1);
+        const int o = yy * W + xx;
+#pragma unroll
+        for (int c3 = 0; c3 < 3; ++c3) {
+            tl[c3][e] = tgt[(size_t)c3 * HW + o];
+            tl[3 + c3][e] = wp0[(size_t)c3 * HW + o];
+            tl[6 + c3][e] = wp1[(size_t)c3 * HW + o];
+        }
+    }
+    __syncthreads();
     float s = 0.f;
-    for (int p = p0 + (int)threadIdx.x; p < p1; p += 256) {
-        const int x = p % W, y = p / W;
+#pragma unroll 1
+    for (int it = 0; it < (PA_TH * PA_TW) / 256; ++it) {
+        const int lp = threadIdx.x + it * 256;
+        const int ly = lp / PA_TW, lx = lp - ly * PA_TW;
+        const int y = y0 + ly, x = x0 + lx;
+        if (y >= H || x >= W) continue;
+        const int p = y * W + x;
+        float cm[2] = {0.f, 0.f}, l1[2] = {0.f, 0.f};   // per frame: sum_c clamp((1-SSIM)/2), sum_c |t - p|
+        float kc[2][9];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float tv[9];
+            float sy = 0.f, syy = 0.f;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                tv[k] = tl[c][(ly + k / 3) * PA_PW + lx + k % 3];
+                sy += tv[k]; syy += tv[k] * tv[k];
+            }
+            const float mu_y = div9(sy);
+            const float sig_y = div9(syy) - mu_y * mu_y;
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                float sx = 0.f, sxx = 0.f, sxy = 0.f, xc = 0.f;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) {
+                    const float xv = tl[3 + f * 3 + c][(ly + k / 3) * PA_PW + lx + k % 3];
+                    if (k == 4) xc = xv;
+                    sx += xv; sxx += xv * xv; sxy += xv * tv[k];
+                }
+                const float mu_x = div9(sx);
+                const float sig_x = div9(sxx) - mu_x * mu_x, sig_xy = div9(sxy) - mu_x * mu_y;
+                const float n1 = 2.f * mu_x * mu_y + C1, n2 = 2.f * sig_xy + C2;
+                const float d1 = mu_x * mu_x + mu_y * mu_y + C1, d2 = sig_x + sig_y + C2;
+                const float inv_d = fast_rcp(d1 * d2);
+                const float S = (n1 * n2) * inv_d;
+                const float raw = (1.f - S) * 0.5f;
+                cm[f] += fminf(fmaxf(raw, 0.f), 1.f);
+                l1[f] += fabsf(tv[4] - xc);
+                if constexpr (TRAIN) {
+                    const float kf = (raw >= 0.f && raw <= 1.f) ? (0.85f / 3.f) * (-0.5f) / 9.f : 0.f;
+                    kc[f][c * 3 + 0] = kf * inv_d * (2.f * mu_y * (n2 - n1) - S * (2.f * mu_x * (d2 - d1)));
+                    kc[f][c * 3 + 1] = kf * inv_d * (-2.f * S * d1);
+                    kc[f][c * 3 + 2] = kf * inv_d * (2.f * n1);
+                }
+            }
+        }
+        const float c2 = (0.85f / 3.f) * cm[0] + (0.15f / 3.f) * l1[0];
+        const float c3 = (0.85f / 3.f) * cm[1] + (0.15f / 3.f) * l1[1];
         float c0 = idmap[((size_t)0 * B + b) * HW + p];
         float c1 = idmap[((size_t)1 * B + b) * HW + p];
         if (noise) { c0 += noise[((size_t)b * 2 + 0) * HW + p]; c1 += noise[((size_t)b * 2 + 1) * HW + p]; }
-        float k2[9], k3[9];
-        const float c2 = photo_px<TRAIN>(warped + ((size_t)0 * B + b) * 3 * HW, target + (size_t)b * 3 * HW, H, W, y, x, k2);
-        const float c3 = photo_px<TRAIN>(warped + ((size_t)1 * B + b) * 3 * HW, target + (size_t)b * 3 * HW, H, W, y, x, k3);
         float m = c0; int k = 0;
         if (c1 < m) { m = c1; k = 1; }
         if (c2 < m) { m = c2; k = 2; }
@@ -89,7 +129,7 @@ __global__ __launch_bounds__(256) void photo_automask_kernel(const float* __rest
         if constexpr (TRAIN) {
             if (k >= 2) {
 #pragma unroll
-                for (int q = 0; q < 9; ++q) coef_sel[(size_t)q * HW + p] = (k == 2) ? k2[q] : k3[q];
+                for (int q = 0; q < 9; ++q) coef_sel[(size_t)q * HW + p] = (k == 2) ? kc[0][q] : kc[1][q];
             }
         }
         s += m;
@@ -212,7 +252,8 @@ __global__ __launch_bounds__(256) void loss_bwd2_kernel(Pyramid pyr, const unsig
             }
             const float du = gix * s.mx, dv = giy * s.my;
             float dp[3];
-            dp[0] = du / den; dp[1] = dv / den; dp[2] = -(du * u + dv * v) / den;
+            const float inv_den = fast_rcp(den);   // u, v above keep the exact quotient: they pick the bilinear cell
+            dp[0] = du * inv_den; dp[1] = dv * inv_den; dp[2] = -(du * u + dv * v) * inv_den;
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 dPacc[fi * 12 + i * 4 + 0] += dp[i] * X[0]; dPacc[fi * 12 + i * 4 + 1] += dp[i] * X[1];
@@ -374,11 +415,19 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(FinalizeArgs a) {
         s_mean[pr] = sum / (float)((a.H >> s) * (a.W >> s));
     }
     __syncthreads();
-    for (int pr = tid; pr < 4 * a.B; pr += 256) {
-        const int s = pr / a.B, b = pr - s * a.B;
+    // 8 lanes per (scale, sample) pair: nblk is one partial per 8 x 64 tile (240 at 192 x 640), a serial chain
+    // of that many dependent-latency loads per thread otherwise
+    for (int pr0 = 0; pr0 < 4 * a.B; pr0 += 32) {
+        const int pr = pr0 + (tid >> 3), kl = tid & 7;
+        const bool live = pr < 4 * a.B;
+        const int s = live ? pr / a.B : 0, b = live ? pr - s * a.B : 0;
         float sum = 0.f;
-        for (int k = 0; k < a.nblk; ++k) sum += a.partial[s][(size_t)b * a.nblk + k];
-        s_rl[pr] = (sum * invHW) * a.sample_w[b];
+        if (live)
+            for (int k = kl; k < a.nblk; k += 8) sum += a.partial[s][(size_t)b * a.nblk + k];
+        sum += wave_shfl_xor(sum, 1);
+        sum += wave_shfl_xor(sum, 2);
+        sum += wave_shfl_xor(sum, 4);
+        if (live && kl == 0) s_rl[pr] = (sum * invHW) * a.sample_w[b];
     }
     // smoothness, reference quirk: term i = flat element i of the batch-flattened gradient maps
     for (int pr = tid; pr < 4 * a.n_smooth; pr += 256) {
@@ -749,7 +798,8 @@ extern "C" int clslam_photo_map(const float* pred, const float* target, float* m
     return check_launch("photo_map");
 }
 
-extern "C" int clslam_automask_blocks(int H, int W) { return std::max(1, std::min(128, cdiv(H * W, 2048))); }
+// Partial sums per (scale, sample) written by the automask kernels = number of 8 x 64 pixel tiles.
+extern "C" int clslam_automask_blocks(int H, int W) { return cdiv(H, PA_TH) * cdiv(W, PA_TW); }
 
 extern "C" int clslam_automask(const float* idmap, const float* noise, const float* rpmap, unsigned char* sel, float* partial,
                                int batch, int H, int W, void* stream) {
@@ -807,13 +857,14 @@ extern "C" int clslam_photo_automask_pyramid(const float* warped, const float* t
                                              void* stream) {
     CLSLAM_REQUIRE(warped && target && idmap && sel && partial && H >= 2 && W >= 2, "photo_automask_pyramid: bad args");
     if (!batch) return CLSLAM_OK;
-    const int nblk = clslam_automask_blocks(H, W);
+    const int nblk = clslam_automask_blocks(H, W);   // = number of 8 x 64 tiles
+    const int tilesX = cdiv(W, PA_TW);
     if (coef_sel)
         hipLaunchKernelGGL(photo_automask_kernel<true>, dim3(nblk, batch, 4), dim3(256), 0, (hipStream_t)stream, warped, target,
-                           idmap, noise, sel, coef_sel, partial, batch, H, W, cdiv(H * W, nblk));
+                           idmap, noise, sel, coef_sel, partial, batch, H, W, tilesX);
     else
         hipLaunchKernelGGL(photo_automask_kernel<false>, dim3(nblk, batch, 4), dim3(256), 0, (hipStream_t)stream, warped, target,
-                           idmap, noise, sel, coef_sel, partial, batch, H, W, cdiv(H * W, nblk));
+                           idmap, noise, sel, coef_sel, partial, batch, H, W, tilesX);
     return check_launch("photo_automask_pyramid");
 }
 

@@ -58,6 +58,8 @@ inline float wave_sum(float v) {
     return v;
 }
 
+inline float fast_rcp(float x) { return 1.f / x; }
+
 inline float wave_shfl_xor(float v, int mask) {
     const int l = lane_id();
     float* s = emu_wave_scratch() + emu_wave_phase() * 128;
