@@ -592,15 +592,24 @@ class Engine:
         if wg is not None:
             wg.wait_stream(main)
 
+        # The weight-gradient kernels add up to about as much GPU time as the dgrad chain itself and the last
+        # (largest-weight) layers only become ready at the very end, so they alternate between the wgrad stream
+        # and the side stream (idle once the short pose-decoder backward is through): two wgrads in flight
+        # instead of a serial tail after the dgrad chain.
+        wg_streams = [wg] if (wg is None or self.side_stream is None) else [wg, self.side_stream]
+        counter = [0]
+
         def on_wg(fn):
-            """run fn on the wgrad stream after everything enqueued so far on the main stream"""
+            """run fn on a wgrad stream after everything enqueued so far on the main stream"""
             if wg is None:
                 fn()
                 return
+            st = wg_streams[counter[0] % len(wg_streams)]
+            counter[0] += 1
             ev = torch.cuda.Event()
             ev.record(main)
-            wg.wait_event(ev)
-            with torch.cuda.stream(wg):
+            st.wait_event(ev)
+            with torch.cuda.stream(st):
                 fn()
 
         if t.wt_ready is not None:

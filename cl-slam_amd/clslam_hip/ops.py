@@ -134,7 +134,7 @@ def make_reduce_table(items, device):
     return torch.from_numpy(rec.view(np.uint8).copy()).to(device)
 
 
-def reduce_multi(table, nitems, stream_ref, blocks_per_item=192):
+def reduce_multi(table, nitems, stream_ref, blocks_per_item=384):
     _lib.get_lib().call('clslam_reduce_multi', table.data_ptr(), nitems, blocks_per_item, _stream(stream_ref))
 
 

@@ -296,13 +296,37 @@ struct ReduceItem { const float* partial; float* out; unsigned long long n; int 
 __global__ __launch_bounds__(256) void reduce_multi_kernel(const ReduceItem* __restrict__ items) {
     __shared__ float4 red[256];
     const ReduceItem it = items[blockIdx.y];
-    // few outputs + many splits (bias gradients: n = 16..256, hundreds of per-block partials): spend the
-    // block's lanes on the split axis instead (16 output lanes x 16 split lanes)
-    const int IL = ((it.n >> 2) <= 16 && (it.n & 3) == 0) ? 16 : 64;
-    const int KL = 256 / IL;
+    // Lanes along the split axis (KL) by split count: the big-weight layers (most of the bytes) have <= 24
+    // splits -> one thread per float4 output sums all of them from independent loads in flight, no LDS, no
+    // barrier; layers with hundreds of splits and few outputs (16/32-channel convs, bias gradients) spend
+    // 4 or 16 lanes per output on the split axis and combine them through LDS in lane order.
+    const int KL = it.splits <= 24 ? ((it.n & 3) ? 4 : 1) : (it.splits <= 96 ? 4 : (it.splits <= 384 ? 16 : 64));
+    const int IL = 256 / KL;
     const int il = threadIdx.x % IL, kl = threadIdx.x / IL;
     if ((it.n & 3) == 0) {   // 16-byte path (all conv weights / biases)
         const size_t n4 = it.n >> 2;
+        if (KL == 1) {
+            for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+                const float4* src = reinterpret_cast<const float4*>(it.partial) + i;
+                float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+                int k = 0;
+                for (; k + 4 <= it.splits; k += 4) {   // four independent loads in flight, summed in split order
+                    const float4 v0 = src[(size_t)k * n4], v1 = src[(size_t)(k + 1) * n4];
+                    const float4 v2 = src[(size_t)(k + 2) * n4], v3 = src[(size_t)(k + 3) * n4];
+                    s.x += v0.x; s.y += v0.y; s.z += v0.z; s.w += v0.w;
+                    s.x += v1.x; s.y += v1.y; s.z += v1.z; s.w += v1.w;
+                    s.x += v2.x; s.y += v2.y; s.z += v2.z; s.w += v2.w;
+                    s.x += v3.x; s.y += v3.y; s.z += v3.z; s.w += v3.w;
+                }
+                for (; k < it.splits; ++k) {
+                    const float4 v = src[(size_t)k * n4];
+                    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+                }
+                s.x *= it.scale; s.y *= it.scale; s.z *= it.scale; s.w *= it.scale;
+                reinterpret_cast<float4*>(it.out)[i] = s;
+            }
+            return;
+        }
         for (size_t i0 = (size_t)blockIdx.x * IL; i0 < n4; i0 += (size_t)gridDim.x * IL) {
             const size_t i = i0 + il;
             float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -330,7 +354,11 @@ __global__ __launch_bounds__(256) void reduce_multi_kernel(const ReduceItem* __r
             for (int k = kl; k < it.splits; k += KL) s += it.partial[(size_t)k * it.n + i];
         red[threadIdx.x].x = s;
         __syncthreads();
-        if (kl == 0 && i < it.n) it.out[i] = (red[il].x + red[IL + il].x + red[2 * IL + il].x + red[3 * IL + il].x) * it.scale;
+        if (kl == 0 && i < it.n) {
+            float t = red[il].x;
+            for (int q = 1; q < KL; ++q) t += red[q * IL + il].x;
+            it.out[i] = t * it.scale;
+        }
         __syncthreads();
     }
 }

@@ -112,3 +112,31 @@ def test_conv_backward_matches_autograd(case, backend):
         dpre = torch.full((B, H, W, Ca), float('nan'), device=dev)
         ops.conv2d(dz_d, wt.view(Ca, taps, Cout), dpre, ksize=k, pad=k // 2, actgrad_src=xa_d, actgrad_kind=act)
     assert rel_err(dpre.cpu(), xa_pre.grad) < 2e-5
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_reduce_multi_all_split_regimes(backend):
+    """clslam_reduce_multi: one launch sums every layer's split partials.  Items cover the three lane
+    layouts (<= 24 splits: one thread per float4 output; <= 96: 4 split lanes; more: 16 split lanes),
+    the tiny-n bias case and the scalar (n % 4 != 0) path."""
+    dev = use_backend(backend)
+    g = torch.Generator().manual_seed(3)
+    shapes = [(4096, 5), (2052, 24), (1024, 40), (256, 96), (64, 300), (16, 1024), (18, 7), (12 * 256 + 1, 3)]
+    total = sum(n for n, _ in shapes)
+    out = torch.full((total,), float('nan'), device=dev)
+    items, refs, off = [], [], 0
+    for n, splits in shapes:
+        part = torch.randn(splits, n, generator=g)
+        items.append((part.to(dev).reshape(-1).contiguous(), out[off:off + n], n, splits))
+        refs.append(part.double().sum(0))
+        off += n
+    table = ops.make_reduce_table(items, dev)
+    ops.reduce_multi(table, len(items), out)
+    got = out.cpu().double()
+    ref = torch.cat(refs)
+    assert torch.isfinite(got).all()
+    assert float((got - ref).abs().max()) < 2e-4 * float(ref.abs().max())
+    again = torch.empty_like(out)
+    items2 = [(p, again[o.storage_offset():o.storage_offset() + n], n, s) for (p, o, n, s) in items]
+    ops.reduce_multi(ops.make_reduce_table(items2, dev), len(items2), again)
+    assert torch.equal(again, out)          # fixed summation order: bitwise reproducible
