@@ -27,7 +27,8 @@ class ConvDesc(C.Structure):
                 ('batch', i32), ('in_h', i32), ('in_w', i32), ('ch_a', i32), ('ch_b', i32),
                 ('out_h', i32), ('out_w', i32), ('ch_out', i32),
                 ('ksize', i32), ('stride', i32), ('pad', i32), ('pad_mode', i32), ('upsample_a', i32),
-                ('act', i32), ('config', i32), ('actgrad_src', fptr), ('actgrad_kind', i32)]
+                ('act', i32), ('config', i32), ('actgrad_src', fptr), ('actgrad_kind', i32),
+                ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t)]
 
 
 class LossDesc(C.Structure):

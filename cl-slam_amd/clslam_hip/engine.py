@@ -127,6 +127,12 @@ class Engine:
         # depth branch leaves idle at kernel tails
         self.side_stream = torch.cuda.Stream(device=device) if device.type == 'cuda' else None
         self.wg_stream = torch.cuda.Stream(device=device) if device.type == 'cuda' else None
+        # split-K scratch of the small-M 3x3 convs: one zero-filled buffer per stream convs are launched on
+        self._conv_ws: Dict[int, torch.Tensor] = {}
+        self.capture_stream = torch.cuda.Stream(device=device) if device.type == 'cuda' else None
+        for st in (self.side_stream, self.wg_stream, self.capture_stream):
+            if st is not None:
+                self._conv_workspace(st.cuda_stream)
         self.depth_first = os.environ.get('CLSLAM_DEPTH_FIRST', '1') != '0'
         self.use_side_stream = os.environ.get('CLSLAM_SIDE_STREAM', '1') != '0'
 
@@ -300,6 +306,18 @@ class Engine:
 
     # ------------------------------------------------------------------------------------------
     # forward pieces
+    CONV_WS_BYTES = 32 << 20
+
+    def _conv_workspace(self, handle: Optional[int] = None) -> None:
+        """Make sure the stream `handle` (default: the current stream) has its split-K scratch registered."""
+        if self.device.type != 'cuda' and handle is None:
+            handle = 0
+        if handle is None:
+            handle = torch.cuda.current_stream(self.device).cuda_stream
+        if handle not in self._conv_ws:
+            self._conv_ws[handle] = torch.zeros(self.CONV_WS_BYTES, dtype=torch.uint8, device=self.device)
+            ops.set_conv_workspace(handle, self._conv_ws[handle])
+
     def _encoder(self, e, bufs, n: int, stem_inputs) -> List[torch.Tensor]:
         """stem_inputs: list of (img_a, img_b|None, batch offset, count); returns the 5 NHWC features."""
         for img_a, img_b, off, cnt in stem_inputs:
@@ -358,6 +376,7 @@ class Engine:
                 draw_noise: bool = True, keep_noise: bool = False) -> Tuple[Dict[Any, torch.Tensor], torch.Tensor]:
         """One _process_batch (dpp.py:906-923).  `inputs` tensors must already live on the device."""
         H, W = self.H, self.W
+        self._conv_workspace()
         aug = {f: self._img(inputs['rgb_aug', f, 0]) for f in (-1, 0, 1)}
         rgb = {f: self._img(inputs['rgb', f, 0]) for f in (-1, 0, 1)}
         B = aug[0].shape[0]
@@ -743,7 +762,7 @@ class Engine:
                 cur.wait_stream(warm)
                 torch.cuda.synchronize(self.device)
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                with torch.cuda.graph(g, stream=self.capture_stream):
                     st.outputs, st.losses = run()
                 st.graph = g
             finally:
@@ -764,6 +783,7 @@ class Engine:
     def run_encoder(self, which: str, x: torch.Tensor) -> List[torch.Tensor]:
         """NCHW feature list of one encoder, as the reference's ResnetEncoder.forward returns it."""
         self.pack_if_needed()
+        self._conv_workspace()
         x = self._img(x.to(self.device))
         n = x.shape[0]
         nimg = 1 if which == 'depth_encoder' else 2
@@ -784,6 +804,7 @@ class Engine:
     def run_pose(self, image_0: torch.Tensor, image_1: torch.Tensor) -> torch.Tensor:
         """predict_pose (dpp.py:628-664): pose_encoder(cat(img0,img1)) -> pose_decoder; returns (n,12)."""
         self.pack_if_needed()
+        self._conv_workspace()
         a, b = self._img(image_0.to(self.device)), self._img(image_1.to(self.device))
         n = a.shape[0]
         key = ('pose', n)

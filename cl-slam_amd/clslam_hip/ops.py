@@ -39,9 +39,23 @@ def _pa(t: Optional[torch.Tensor], dtype):
     return t.data_ptr()
 
 
+# split-K scratch per stream (stream handle -> zero-initialised uint8 tensor), see clslam_conv_desc.workspace
+_CONV_WORKSPACES = {}
+
+
+def set_conv_workspace(stream_handle: int, workspace: Optional[torch.Tensor]) -> None:
+    """Register the split-K scratch conv2d() uses for launches on `stream_handle` (None: drop it).  The
+    tensor must be zero-filled once and used by that stream only."""
+    if workspace is None:
+        _CONV_WORKSPACES.pop(stream_handle, None)
+    else:
+        assert workspace.dtype == torch.uint8 and workspace.is_contiguous()
+        _CONV_WORKSPACES[stream_handle] = workspace
+
+
 def conv2d(src_a, weight, out, *, src_b=None, scale=None, shift=None, residual=None, ksize=3, stride=1,
            pad=None, pad_mode=PAD_ZERO, upsample_a=False, act=ACT_NONE, config=-1, actgrad_src=None,
-           actgrad_kind=ACT_NONE):
+           actgrad_kind=ACT_NONE, workspace=None):
     """src_a (B,Ha,Wa,Ca) NHWC; weight (Cout, k*k, Ca+Cb); out (B,Ho,Wo,Cout)."""
     B, Ho, Wo, Cout = out.shape
     Ha, Wa, Ca = src_a.shape[1:]
@@ -50,9 +64,13 @@ def conv2d(src_a, weight, out, *, src_b=None, scale=None, shift=None, residual=N
     if pad is None:
         pad = ksize // 2
     assert weight.shape[0] == Cout and weight.numel() == Cout * ksize * ksize * (Ca + Cb), weight.shape
+    stream = _stream(out)
+    if workspace is None and _CONV_WORKSPACES:
+        workspace = _CONV_WORKSPACES.get(stream.value or 0)
     d = _lib.ConvDesc(_p(src_a), _p(src_b), _p(weight), _p(scale), _p(shift), _p(residual), _p(out),
                       B, Hi, Wi, Ca, Cb, Ho, Wo, Cout, ksize, stride, pad, pad_mode, int(upsample_a), act, config,
-                      _p(actgrad_src), actgrad_kind)
+                      _p(actgrad_src), actgrad_kind, None if workspace is None else workspace.data_ptr(),
+                      0 if workspace is None else workspace.numel())
     if PROFILE is not None:
         cfg = config if config >= 0 else _lib.get_lib().cdll.clslam_conv2d_pick_config(C.byref(d))
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -75,7 +93,7 @@ def conv_desc(src_a, out_shape, *, src_b=None, ksize=3, stride=1, pad=None, pad_
     if pad is None:
         pad = ksize // 2
     return _lib.ConvDesc(_p(src_a), _p(src_b), None, None, None, None, None, B, Hi, Wi, Ca, Cb, Ho, Wo, Cout,
-                         ksize, stride, pad, pad_mode, int(upsample_a), ACT_NONE, -1, None, ACT_NONE)
+                         ksize, stride, pad, pad_mode, int(upsample_a), ACT_NONE, -1, None, ACT_NONE, None, 0)
 
 
 def weight_transpose(w, wt, ch_in_sel=None):

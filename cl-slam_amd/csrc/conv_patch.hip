@@ -17,6 +17,8 @@
 
 namespace clslam {
 
+constexpr int kSplitKMaxTiles = 16384;   // counters at the head of the caller's workspace (64 KiB)
+
 struct PatchK {
     const float* __restrict__ src_a;
     const float* __restrict__ src_b;
@@ -31,6 +33,14 @@ struct PatchK {
     int pad, pad_mode, ups, act;
     int tilesX, tilesY, tilesN, nblk;
     int n_fastest;   // block order inside an XCD: 1 = the output-channel tiles of one spatial tile are adjacent
+    // split-K (small-M layers: too few tiles to fill 256 CUs).  ksplit blocks share an output tile, each
+    // reducing a contiguous range of input-channel chunks; they park their raw accumulators in ws
+    // [split][tile][BM*BN] and the LAST one to arrive (device-scope counter per tile) sums the ksplit
+    // slabs in split order -- deterministic whichever block that is -- and runs the epilogue.
+    int ksplit;
+    float* ws;
+    unsigned* counters;   // [tiles], zero on entry, reset by the finishing block
+    size_t ws_bytes;      // host side only
 };
 
 // RUN = true ("run tiles", for narrow images such as the 6x20 / 12x40 layers where a 4x16 rectangle
@@ -38,7 +48,9 @@ struct PatchK {
 // the patch is the full-width band of input rows it touches (runtime PH x (Wo+2), bounded by run_pp(BM)).
 constexpr int run_pp(int bm) { return bm <= 64 ? 224 : 320; }
 
-template <int TH, int TW, int BN, int BK, int MF, int WGM, bool RUN, int LDPAD, int S>
+// SK: split-K instantiation (its extra live registers cost the plain kernel a wave of occupancy: 96 -> 100
+// VGPRs crosses the 5-waves/SIMD allocation boundary, so the unsplit path is compiled without it)
+template <int TH, int TW, int BN, int BK, int MF, int WGM, bool RUN, int LDPAD, int S, bool SK>
 __global__ __launch_bounds__(256) void conv3x3_patch_kernel(PatchK p) {
     constexpr int BM = TH * TW;
     constexpr int PH = (TH - 1) * S + 3, PW = (TW - 1) * S + 3, PP = RUN ? run_pp(BM) : PH * PW;   // S = conv stride
@@ -65,6 +77,10 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(PatchK p) {
     // re-read from L2 by the other tiles; with large weights (layer3/4) the spatial tiles of one channel
     // tile are adjacent instead (the weight slab stays in L2, the small input does anyway).
     int logical = xcd_remap((int)blockIdx.x, p.nblk);
+    const int tiles_total = SK ? p.nblk / p.ksplit : p.nblk;
+    const int split = SK ? logical / tiles_total : 0;
+    if (SK) logical -= split * tiles_total;
+    const int tile_id = logical;
     int tn;
     if (p.n_fastest) { tn = logical % p.tilesN; logical /= p.tilesN; }
     const int tx = logical % p.tilesX; logical /= p.tilesX;
@@ -183,12 +199,14 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(PatchK p) {
         }
     }
 
-    load_global(0);
-    for (int c0 = 0; c0 < Cin; c0 += BK) {
+    const int cps = SK ? (Cin / BK + p.ksplit - 1) / p.ksplit : Cin / BK;   // channel chunks per split
+    const int c_begin = SK ? split * cps * BK : 0, c_end = SK ? min(Cin, c_begin + cps * BK) : Cin;
+    if (c_begin < c_end) load_global(c_begin);
+    for (int c0 = c_begin; c0 < c_end; c0 += BK) {
         __syncthreads();           // previous chunk's MFMAs are done with LDS
         store_lds();
         __syncthreads();
-        if (c0 + BK < Cin) load_global(c0 + BK);
+        if (c0 + BK < c_end) load_global(c0 + BK);
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int ky = tap / 3, kx = tap - ky * 3;
@@ -217,6 +235,46 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(PatchK p) {
                 }
             }
         }
+    }
+
+    // ---- split-K: park the partial tile, the last block of the tile gathers all of them -------------
+    if constexpr (SK) {
+        __shared__ int s_last;
+        float* slab = p.ws + ((size_t)split * tiles_total + tile_id) * (BM * BN);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < NACC; ++r) {
+                    int row;
+                    if constexpr (MF == 32) row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    else row = 4 * (lane >> 4) + r;
+                    coherent_store(&slab[(wm0 + i * MF + row) * BN + wn0 + j * MF + (lane % MF)],
+                                   NCH == 2 ? acc[i][j][0][r] + acc[i][j][NCH - 1][r] : acc[i][j][0][r]);
+                }
+        stores_complete();      // every lane's slab stores are acknowledged ...
+        __syncthreads();        // ... before the block announces itself
+        if (tid == 0) s_last = (coherent_inc(&p.counters[tile_id]) == (unsigned)(p.ksplit - 1));
+        __syncthreads();
+        if (!s_last) return;
+        if (tid == 0) coherent_store_u32(&p.counters[tile_id], 0u);   // ready for the next launch on this stream
+        const float* gather = p.ws + (size_t)tile_id * (BM * BN);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < NACC; ++r) {
+                    int row;
+                    if constexpr (MF == 32) row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    else row = 4 * (lane >> 4) + r;
+                    const int e = (wm0 + i * MF + row) * BN + wn0 + j * MF + (lane % MF);
+                    float sum = 0.f;
+                    for (int sp = 0; sp < p.ksplit; ++sp) sum += coherent_load(&gather[(size_t)sp * tiles_total * (BM * BN) + e]);
+                    acc[i][j][0][r] = sum;
+                    if (NCH == 2) acc[i][j][NCH - 1][r] = 0.f;
+                }
     }
 
     // ---- epilogue --------------------------------------------------------------------------------
@@ -253,7 +311,8 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(PatchK p) {
     }
 }
 
-template <int TH, int TW, int BN, int BK, int MF, int WGM, bool RUN = false, int LDPAD = 4, int S = 1>
+// SKOK: the configuration has a split-K instantiation (the small-M ones: 20-23)
+template <int TH, int TW, int BN, int BK, int MF, int WGM, bool RUN = false, int LDPAD = 4, int S = 1, bool SKOK = false>
 static int launch_patch(PatchK k, hipStream_t stream) {
     if (RUN) {
         const int spanned = (TH * TW - 1 + k.Wo - 1) / k.Wo + 1;
@@ -262,17 +321,34 @@ static int launch_patch(PatchK k, hipStream_t stream) {
     k.tilesX = RUN ? cdiv(k.Ho * k.Wo, TH * TW) : cdiv(k.Wo, TW);
     k.tilesY = RUN ? 1 : cdiv(k.Ho, TH);
     k.tilesN = cdiv(k.Cout, BN);
-    k.nblk = k.tilesX * k.tilesY * k.tilesN * k.B;
+    const int tiles = k.tilesX * k.tilesY * k.tilesN * k.B;
+    // Split-K is OFF unless CLSLAM_SPLITK=<n> asks for it.  Measured on MI355X, standalone, 3 splits:
+    // layer4 512->512 @6x20 57 -> 43 us (B=5), 80 -> 75 us (B=10), upconv_4_0 38 -> 26 us; more splits lose
+    // again (slab traffic, per-block prologue) and the 256-channel layers do not gain.  Inside the adapt
+    // step, where these convs overlap the other branch's kernels, the step time did not move (275.4 vs
+    // 275.1 frames/s), so the heuristic stays conservative; the path is kept for B=1 serving-style use.
+    const int chunks = (k.Ca + k.Cb) / BK;
+    int ksplit = 1;
+    if (const char* e = getenv("CLSLAM_SPLITK")) { if (k.ws) ksplit = std::max(1, std::min(atoi(e), chunks)); }
+    if (!SKOK || (size_t)ksplit * tiles * (TH * TW * BN) * sizeof(float) > k.ws_bytes || tiles > kSplitKMaxTiles) ksplit = 1;
+    k.ksplit = ksplit;
+    k.nblk = tiles * ksplit;
     k.n_fastest = ((size_t)k.Cout * 9 * (k.Ca + k.Cb) * 4 <= (size_t)(2 << 20)) ? 1 : 0;
     if (const char* e = getenv("CLSLAM_N_FASTEST")) k.n_fastest = atoi(e);
-    hipLaunchKernelGGL((conv3x3_patch_kernel<TH, TW, BN, BK, MF, WGM, RUN, LDPAD, S>), dim3(k.nblk), dim3(256), 0, stream, k);
+    if constexpr (SKOK) {
+        if (ksplit > 1) {
+            hipLaunchKernelGGL((conv3x3_patch_kernel<TH, TW, BN, BK, MF, WGM, RUN, LDPAD, S, true>), dim3(k.nblk), dim3(256), 0, stream, k);
+            return check_launch("conv3x3_patch(split-K)");
+        }
+    }
+    hipLaunchKernelGGL((conv3x3_patch_kernel<TH, TW, BN, BK, MF, WGM, RUN, LDPAD, S, false>), dim3(k.nblk), dim3(256), 0, stream, k);
     return check_launch("conv3x3_patch");
 }
 
 // Called by clslam_conv2d for configs >= 10.
 int conv3x3_patch_dispatch(const clslam_conv_desc* d, int cfg, hipStream_t stream) {
     const int st = d->stride;
-    if (d->ksize != 3 || (st != 1 && st != 2) || (st == 2) != (cfg == 23)) {
+    if (d->ksize != 3 || (st != 1 && st != 2) || (st == 2) != (cfg == 23) || ((cfg == 24 || cfg == 25) && (d->ch_a + d->ch_b) % 32 != 0)) {
         set_error("conv2d: patch configs need a 3x3 conv with stride 1 (configs 10-22) or 2 (config 23)");
         return CLSLAM_ERR_INVALID;
     }
@@ -286,6 +362,12 @@ int conv3x3_patch_dispatch(const clslam_conv_desc* d, int cfg, hipStream_t strea
     k.B = d->batch; k.Hi = d->in_h; k.Wi = d->in_w; k.Ca = d->ch_a; k.Cb = d->ch_b; k.Ho = d->out_h; k.Wo = d->out_w;
     k.Cout = d->ch_out; k.pad = d->pad; k.pad_mode = d->pad_mode; k.ups = d->upsample_a; k.act = d->act;
     k.tilesX = k.tilesY = k.tilesN = k.nblk = 0; k.n_fastest = 0;
+    k.ksplit = 1; k.ws = nullptr; k.counters = nullptr; k.ws_bytes = 0;
+    if (d->workspace && d->workspace_bytes > (size_t)kSplitKMaxTiles * sizeof(unsigned)) {
+        k.counters = (unsigned*)d->workspace;
+        k.ws = (float*)((char*)d->workspace + (size_t)kSplitKMaxTiles * sizeof(unsigned));
+        k.ws_bytes = d->workspace_bytes - (size_t)kSplitKMaxTiles * sizeof(unsigned);
+    }
     switch (cfg) {
         case 10: return launch_patch<8, 16, 64, 16, 32, 2>(k, stream);   // 128 px x 64 ch, 32x32x2
         case 11: return launch_patch<8, 16, 32, 16, 32, 4>(k, stream);   // 128 px x 32 ch
@@ -297,10 +379,12 @@ int conv3x3_patch_dispatch(const clslam_conv_desc* d, int cfg, hipStream_t strea
         case 17: return launch_patch<4, 16, 16, 16, 16, 4>(k, stream);   //  64 px x 16 ch (small images)
         case 18: return launch_patch<4, 16, 16, 16, 16, 4, true>(k, stream);   // 64-px runs x 16 ch (narrow images)
         case 19: return launch_patch<8, 16, 16, 16, 16, 4, true>(k, stream);   // 128-px runs x 16 ch
-        case 20: return launch_patch<8, 16, 16, 16, 16, 4, false, 8>(k, stream);  // = 12 with conflict-free rows
-        case 21: return launch_patch<4, 16, 16, 16, 16, 4, false, 8>(k, stream);  // = 17 with conflict-free rows
-        case 22: return launch_patch<4, 16, 16, 16, 16, 4, true, 8>(k, stream);   // = 18 with conflict-free rows
-        case 23: return launch_patch<4, 16, 16, 16, 16, 4, false, 8, 2>(k, stream);  // stride-2 convs (encoder stage entries)
+        case 20: return launch_patch<8, 16, 16, 16, 16, 4, false, 8, 1, true>(k, stream);  // = 12 with conflict-free rows
+        case 21: return launch_patch<4, 16, 16, 16, 16, 4, false, 8, 1, true>(k, stream);  // = 17 with conflict-free rows
+        case 22: return launch_patch<4, 16, 16, 16, 16, 4, true, 8, 1, true>(k, stream);   // = 18 with conflict-free rows
+        case 23: return launch_patch<4, 16, 16, 16, 16, 4, false, 8, 2, true>(k, stream);  // stride-2 convs (encoder stage entries)
+        case 24: return launch_patch<4, 16, 16, 32, 16, 4, true, 8>(k, stream);   // = 22 with BK = 32 (half the chunks: latency-bound layers)
+        case 25: return launch_patch<4, 16, 16, 32, 16, 4, false, 8>(k, stream);  // = 21 with BK = 32
         default: set_error("conv2d: unknown patch config %d", cfg); return CLSLAM_ERR_INVALID;
     }
 }

@@ -45,6 +45,18 @@ __device__ __forceinline__ float wave_sum(float v) {
            (__builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 48)));
 }
 
+// Cross-workgroup hand-off inside one kernel (split-K gather).  MI355X has one L2 per XCD and they are
+// not coherent with each other for ordinary accesses; a device-scope __threadfence() makes them so by
+// writing back / invalidating the whole L2 (measured: ~300 us per conv when 1280 workgroups do it).
+// Agent-scope relaxed atomics instead carry the scope on the instruction itself (sc1): the store is
+// written through to the coherence point, the load bypasses non-coherent lines -- no cache-wide
+// maintenance.  stores_complete() waits until this lane's stores have been acknowledged.
+__device__ __forceinline__ void coherent_store(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float coherent_load(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void coherent_store_u32(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned coherent_inc(unsigned* p) { return __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void stores_complete() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 // 1/x to 1 ulp (v_rcp_f32) -- for the SSIM / projection quotients of the loss kernels, where an IEEE
 // division costs ~10 instructions and the last ulp is far below the 1e-4 parity bar
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }

@@ -70,6 +70,13 @@ typedef struct clslam_conv_desc {
      * activation being differentiated (ReLU' = y>0, ELU' = y>0 ? 1 : y+1). NULL = off.        */
     const float* actgrad_src;
     int32_t actgrad_kind;
+    /* Optional split-K scratch for the small-M 3x3 layers (layer3/4, pose decoder, upconv_4_x at 192x640:
+     * fewer output tiles than CUs).  Device memory, ZERO-FILLED ONCE by the caller, private to the
+     * stream the conv is launched on (convs on one stream may share it: the first 64 KiB are per-tile
+     * arrival counters that every launch leaves at zero).  NULL/0: no split-K.  Results do not depend on
+     * which workgroup finishes last: partial tiles are summed in split order.                       */
+    void* workspace;
+    size_t workspace_bytes;
 } clslam_conv_desc;
 int clslam_conv2d(const clslam_conv_desc* desc, void* stream);
 /* the tile configuration clslam_conv2d uses for desc->config < 0 (profiling / reporting) */

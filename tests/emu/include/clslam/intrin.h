@@ -60,6 +60,13 @@ inline float wave_sum(float v) {
 
 inline float fast_rcp(float x) { return 1.f / x; }
 
+// blocks run on several host threads: real atomics / fences
+inline void coherent_store(float* p, float v) { __atomic_store(p, &v, __ATOMIC_RELAXED); }
+inline float coherent_load(const float* p) { float v; __atomic_load(p, &v, __ATOMIC_RELAXED); return v; }
+inline void coherent_store_u32(unsigned* p, unsigned v) { __atomic_store_n(p, v, __ATOMIC_SEQ_CST); }
+inline unsigned coherent_inc(unsigned* p) { return __atomic_fetch_add(p, 1u, __ATOMIC_SEQ_CST); }
+inline void stores_complete() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+
 inline float wave_shfl_xor(float v, int mask) {
     const int l = lane_id();
     float* s = emu_wave_scratch() + emu_wave_phase() * 128;

@@ -65,6 +65,8 @@ using std::min;
 using std::max;
 inline float __expf(float x) { return expf(x); }
 inline float __fdividef(float a, float b) { return a / b; }
+inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
+inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 inline float atomicAdd(float* p, float v) {
     float old = 0.f;
     // fp atomic add via CAS on the bit pattern

@@ -91,3 +91,47 @@ def test_conv2d_matches_torch(case, backend):
                stride=stride, pad=pad, pad_mode=pad_mode, upsample_a=ups, act=act, config=config)
     assert rel_err(out.cpu(), ref) < 2e-5, rel_err(out.cpu(), ref)
 
+
+
+# B, H, W, Ca, Cb, Cout, stride, pad_mode, ups, act, resid, config
+SPLITK_CASES = [
+    (1, 6, 20, 128, 0, 32, 1, 0, False, 1, True, 22),     # layer4-like run tiles, 8 chunks -> 2 splits
+    (2, 6, 20, 256, 0, 48, 1, 0, False, 1, False, 22),    # 16 chunks -> 4 splits, ragged Cout
+    (1, 12, 40, 128, 128, 32, 1, 1, True, 2, False, 21),  # upconv_4_1-like: upsample + concat, reflect
+    (1, 13, 21, 128, 0, 32, 2, 0, False, 1, False, 23),   # stride-2 stage entry
+    (1, 8, 16, 144, 0, 16, 1, 0, False, 0, False, 20),    # 9 chunks over 2 splits (5 + 4)
+]
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+@pytest.mark.parametrize('case', SPLITK_CASES)
+def test_conv2d_split_k(backend, case, monkeypatch):
+    """Split-K of the LDS-patch kernel (clslam_conv_desc.workspace; the heuristic only splits 512-channel
+    reductions, CLSLAM_SPLITK forces a split count): same result as torch, the scratch's
+    arrival counters are back at zero afterwards (a second launch on the same scratch agrees bitwise),
+    and the result matches the unsplit launch to fp32 reassociation."""
+    dev = use_backend(backend)
+    B, H, W, Ca, Cb, Cout, stride, pad_mode, ups, act, resid, config = case
+    g = torch.Generator().manual_seed(11)
+    Ha, Wa = (H // 2, W // 2) if ups else (H, W)
+    xa = torch.randn(B, Ha, Wa, Ca, generator=g)
+    xb = torch.randn(B, H, W, Cb, generator=g) if Cb else None
+    w = torch.randn(Cout, 9, Ca + Cb, generator=g) * 0.05
+    scale, shift = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.1
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    res = torch.randn(B, Ho, Wo, Cout, generator=g) if resid else None
+    ref = _ref_conv(xa, w, xb=xb, scale=scale, shift=shift, residual=res, ksize=3, stride=stride, pad=1, pad_mode=pad_mode,
+                    ups=ups, act=act)
+    t = lambda v: None if v is None else v.to(dev)   # noqa: E731
+    ws = torch.zeros(4 << 20, dtype=torch.uint8, device=dev)
+    monkeypatch.setenv('CLSLAM_SPLITK', '3' if Ca + Cb >= 256 else '2')
+    outs = []
+    for workspace in (ws, ws, None):
+        out = torch.full((B, Ho, Wo, Cout), float('nan'), device=dev)
+        ops.conv2d(t(xa), t(w), out, src_b=t(xb), scale=t(scale), shift=t(shift), residual=t(res), ksize=3, stride=stride,
+                   pad_mode=pad_mode, upsample_a=ups, act=act, config=config, workspace=workspace)
+        outs.append(out.cpu())
+    assert rel_err(outs[0], ref) < 2e-5
+    assert torch.equal(outs[0], outs[1])
+    assert rel_err(outs[0], outs[2]) < 1e-5 and not torch.equal(outs[0], outs[2])   # split really happened
+    assert int(ws[:65536].view(torch.int32).abs().sum()) == 0

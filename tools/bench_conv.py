@@ -19,6 +19,12 @@ LAYERS = [
     ('layer3 256->256 @12x40', 1, 12, 40, 256, 0, 256, 3, 1, 0, 0),
     ('layer4 512->512 @6x20', 1, 6, 20, 512, 0, 512, 3, 1, 0, 0),
     ('layer4 pose 2B', 2, 6, 20, 512, 0, 512, 3, 1, 0, 0),
+    ('layer3 pose 2B', 2, 12, 40, 256, 0, 256, 3, 1, 0, 0),
+    ('layer3.0 128->256 s2', 1, 24, 80, 128, 0, 256, 3, 2, 0, 0),
+    ('layer4.0 256->512 s2', 1, 12, 40, 256, 0, 512, 3, 2, 0, 0),
+    ('pose dec 256->256 2B', 2, 6, 20, 256, 0, 256, 3, 1, 0, 0),
+    ('upconv_4_0 512->256 @6x20', 1, 6, 20, 512, 0, 256, 3, 1, 1, 0),
+    ('upconv_3_0 256->128 @12x40', 1, 12, 40, 256, 0, 128, 3, 1, 1, 0),
     ('layer2.0 64->128 s2', 1, 48, 160, 64, 0, 128, 3, 2, 0, 0),
     ('upconv_4_1 512->256 @12x40', 1, 12, 40, 256, 256, 256, 3, 1, 1, 1),
     ('upconv_3_1 256->128 @24x80', 1, 24, 80, 128, 128, 128, 3, 1, 1, 1),
@@ -54,12 +60,16 @@ for name, bm, Hi, Wi, Ca, Cb, Cout, k, stride, refl, ups in LAYERS:
     out = torch.empty(Bn, Ho, Wo, Cout, device=dev)
     flops = 2.0 * Bn * Ho * Wo * Cout * k * k * (Ca + Cb)
     line = f'{name:32s} M={Bn*Ho*Wo:7d} {flops/1e9:7.2f} GF |'
-    cfgs = [-1]
+    cfgs = [-1] + ([24, 25] if (stride == 1 and k == 3 and (Ca + Cb) % 32 == 0 and Hi <= 24) else [])
+    wsk = torch.zeros(32 << 20, dtype=torch.uint8, device=dev)
     for cfg in cfgs:
         try:
             t = timeit(lambda: ops.conv2d(xa, w, out, src_b=xb, ksize=k, stride=stride, pad_mode=refl, upsample_a=bool(ups),
                                           act=1, config=cfg))
             line += f' c{cfg}:{flops/t/1e12:6.1f}'
+            t = timeit(lambda: ops.conv2d(xa, w, out, src_b=xb, ksize=k, stride=stride, pad_mode=refl, upsample_a=bool(ups),
+                                          act=1, config=cfg, workspace=wsk))
+            line += f' splitK:{flops/t/1e12:6.1f}'
         except Exception:
             line += f' c{cfg}:   -  '
     # wgrad
