@@ -202,6 +202,33 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(PatchK p) {
     const int cps = SK ? (Cin / BK + p.ksplit - 1) / p.ksplit : Cin / BK;   // channel chunks per split
     const int c_begin = SK ? split * cps * BK : 0, c_end = SK ? min(Cin, c_begin + cps * BK) : Cin;
     if (c_begin < c_end) load_global(c_begin);
+    // Epilogue operands are fetched now, behind the first chunk: loading them after the main loop puts one
+    // or two dependent memory latencies (~1-2 us each) on the tail of every block.
+    float scv[TN], shv[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = min(n0 + wn0 + j * MF + (lane % MF), p.Cout - 1);
+        scv[j] = p.scale ? p.scale[n] : 1.f;
+        shv[j] = p.shift ? p.shift[n] : 0.f;
+    }
+    constexpr bool PRE_RES = (TM * TN * NACC <= 4) && !SK && RUN;   // only where it does not cost a wave of occupancy
+    float resv[PRE_RES ? TM * TN * NACC : 1];
+    if constexpr (PRE_RES) {
+#pragma unroll
+        for (int r = 0; r < NACC; ++r) {
+            const int m = wm0 + 4 * (lane >> 4) + r;
+            int oy, ox;
+            bool ok = true;
+            if constexpr (RUN) {
+                const int mm = min(m0 + m, p.Ho * p.Wo - 1);
+                oy = mm / p.Wo; ox = mm % p.Wo;
+            } else {
+                oy = min(oy0 + m / TW, p.Ho - 1); ox = min(ox0 + m % TW, p.Wo - 1);
+            }
+            const int n = min(n0 + wn0 + (lane % MF), p.Cout - 1);
+            resv[r] = p.residual ? p.residual[(((size_t)b * p.Ho + oy) * p.Wo + ox) * p.Cout + n] : 0.f;
+        }
+    }
     for (int c0 = c_begin; c0 < c_end; c0 += BK) {
         __syncthreads();           // previous chunk's MFMAs are done with LDS
         store_lds();
@@ -284,8 +311,7 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(PatchK p) {
         for (int j = 0; j < TN; ++j) {
             const int n = n0 + wn0 + j * MF + (lane % MF);
             if (n >= p.Cout) continue;
-            const float sc = p.scale ? p.scale[n] : 1.f;
-            const float sh = p.shift ? p.shift[n] : 0.f;
+            const float sc = scv[j], sh = shv[j];
 #pragma unroll
             for (int r = 0; r < NACC; ++r) {
                 int row;
@@ -302,7 +328,8 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(PatchK p) {
                 }
                 const size_t o = (((size_t)b * p.Ho + oy) * p.Wo + ox) * p.Cout + n;
                 float v = (NCH == 2 ? acc[i][j][0][r] + acc[i][j][NCH - 1][r] : acc[i][j][0][r]) * sc + sh;
-                if (p.residual) v += p.residual[o];
+                if constexpr (PRE_RES) v += resv[r];
+                else if (p.residual) v += p.residual[o];
                 v = apply_act(v, p.act);
                 if (p.actgrad_src) v *= act_grad_from_output(p.actgrad_src[o], p.actgrad_kind);
                 p.out[o] = v;

@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
                                                         int B, int H, int W, int Cin, int Ho, int Wo, int tiles_x,
                                                         int tiles_y) {
     __shared__ float patch[ST_CG * ST_PH * ST_PW];
-    __shared__ float Ws[64 * ST_LDW];
+    __shared__ __attribute__((aligned(16))) float Ws[64 * ST_LDW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int bid = blockIdx.x;
     const int tx = bid % tiles_x; bid /= tiles_x;
@@ -52,21 +52,45 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
 
     // one pass per group of 3 input channels (depth net: 1 pass, pose net: 2): stage the 3 x 21 x 37
     // normalised patch and the 64 x 147 weight slab, then 74 MFMA k-steps without further barriers
+    constexpr int P_N = ST_CG * ST_PH * ST_PW, P_IT = (P_N + 255) / 256;      // 2331 patch elements, 10 per thread
+    constexpr int W_N4 = 64 * ST_LDW / 4, W_IT = (W_N4 + 255) / 256;         // 2384 float4 of weights, 10 per thread
+    static_assert(64 * ST_LDW % 4 == 0, "weight slab is copied as float4");
     for (int c0 = 0; c0 < Cin; c0 += ST_CG) {
-        __syncthreads();
-        for (int e = tid; e < ST_CG * ST_PH * ST_PW; e += 256) {
-            const int c = e / (ST_PH * ST_PW), rem = e - c * (ST_PH * ST_PW);
+        // All global loads of the pass are issued back to back into registers (20 independent loads in
+        // flight per thread), then written to LDS: a load->store loop pays the memory latency ~10x per block.
+        float pv[P_IT];
+        bool pok[P_IT];
+#pragma unroll
+        for (int it = 0; it < P_IT; ++it) {
+            const int e = tid + it * 256;
+            const int ee = e < P_N ? e : 0;
+            const int c = ee / (ST_PH * ST_PW), rem = ee - c * (ST_PH * ST_PW);
             const int r = rem / ST_PW, q = rem - r * ST_PW;
             const int iy = iy0 + r, ix = ix0 + q;
             const int cc = c0 + c;
             const float* img = (cc < 3) ? img_a + ((size_t)b * 3 + cc) * H * W : img_b + ((size_t)b * 3 + (cc - 3)) * H * W;
-            const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
-            const float raw = img[ok ? (size_t)iy * W + ix : 0];
-            patch[e] = ok ? (raw - 0.45f) / 0.225f : 0.f;
+            pok[it] = iy >= 0 && iy < H && ix >= 0 && ix < W;
+            pv[it] = img[pok[it] ? (size_t)iy * W + ix : 0];
         }
         // weight slab of this pass, pre-packed by the host in the LDS image [64][ST_LDW] (zero padded)
-        const float* wp = w + (size_t)(c0 / ST_CG) * 64 * ST_LDW;
-        for (int e = tid; e < 64 * ST_LDW; e += 256) Ws[e] = wp[e];
+        const float4* wp4 = reinterpret_cast<const float4*>(w + (size_t)(c0 / ST_CG) * 64 * ST_LDW);
+        float4 wv[W_IT];
+#pragma unroll
+        for (int it = 0; it < W_IT; ++it) {
+            const int e = tid + it * 256;
+            wv[it] = wp4[e < W_N4 ? e : 0];
+        }
+        __syncthreads();   // previous pass's MFMAs are done with LDS
+#pragma unroll
+        for (int it = 0; it < P_IT; ++it) {
+            const int e = tid + it * 256;
+            if (e < P_N) patch[e] = pok[it] ? (pv[it] - 0.45f) / 0.225f : 0.f;
+        }
+#pragma unroll
+        for (int it = 0; it < W_IT; ++it) {
+            const int e = tid + it * 256;
+            if (e < W_N4) reinterpret_cast<float4*>(Ws)[e] = wv[it];
+        }
         __syncthreads();
 #pragma unroll
         for (int s = 0; s < (ST_K + 1) / 2; ++s) {
