@@ -73,8 +73,8 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
             pv[it] = img[pok[it] ? (size_t)iy * W + ix : 0];
         }
         // weight slab of this pass, pre-packed by the host in the LDS image [64][ST_LDW] (zero padded)
-        const float4* wp4 = reinterpret_cast<const float4*>(w + (size_t)(c0 / ST_CG) * 64 * ST_LDW);
-        float4 wv[W_IT];
+        const f32x4* wp4 = reinterpret_cast<const f32x4*>(w + (size_t)(c0 / ST_CG) * 64 * ST_LDW);
+        f32x4 wv[W_IT];   // native vector type: the HIP float4 struct array ended up in scratch here
 #pragma unroll
         for (int it = 0; it < W_IT; ++it) {
             const int e = tid + it * 256;
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
 #pragma unroll
         for (int it = 0; it < W_IT; ++it) {
             const int e = tid + it * 256;
-            if (e < W_N4) reinterpret_cast<float4*>(Ws)[e] = wv[it];
+            if (e < W_N4) reinterpret_cast<f32x4*>(Ws)[e] = wv[it];
         }
         __syncthreads();
 #pragma unroll

@@ -141,19 +141,34 @@ __global__ __launch_bounds__(256) void dispconv_wgrad_kernel(const float* __rest
 __global__ __launch_bounds__(256) void pose_head_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w2,
                                                             const float* __restrict__ b2, float* __restrict__ mean,
                                                             float* __restrict__ pose, int HW) {
+    // thread = (channel quad c4, pixel lane pl): 16-byte loads, four independent pixel lanes per channel quad,
+    // combined in lane order; then 16 lanes per output row for the 12x256 matvec.  (One thread per channel
+    // walking all pixels was a ~30 us serial chain at the very end of the pose branch.)
+    __shared__ float4 part[4][64];
     __shared__ float ms[256];
-    const int n = blockIdx.x, c = threadIdx.x;
-    float s = 0.f;
-    for (int p = 0; p < HW; ++p) s += x[((size_t)n * HW + p) * 256 + c];
-    s = s / (float)HW;
-    ms[c] = s;
-    mean[(size_t)n * 256 + c] = s;
-    __syncthreads();
-    if (c < 12) {
-        float a = 0.f;
-        for (int k = 0; k < 256; ++k) a = fmaf(w2[c * 256 + k], ms[k], a);
-        pose[n * 12 + c] = 0.01f * (a + b2[c]);
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const int c4 = tid & 63, pl = tid >> 6;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int p = pl; p < HW; p += 4) {
+        const float4 v = *reinterpret_cast<const float4*>(x + ((size_t)n * HW + p) * 256 + c4 * 4);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
+    part[pl][c4] = s;
+    __syncthreads();
+    if (tid < 64) {
+        float4 t = part[0][tid];
+        for (int k = 1; k < 4; ++k) { const float4 v = part[k][tid]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+        t.x /= (float)HW; t.y /= (float)HW; t.z /= (float)HW; t.w /= (float)HW;
+        *reinterpret_cast<float4*>(&ms[tid * 4]) = t;
+        *reinterpret_cast<float4*>(mean + (size_t)n * 256 + tid * 4) = t;
+    }
+    __syncthreads();
+    const int o = tid >> 4, kk = tid & 15;     // 16 output groups (12 used) x 16 lanes
+    float a = 0.f;
+    if (o < 12)
+        for (int k = kk; k < 256; k += 16) a = fmaf(w2[o * 256 + k], ms[k], a);
+    a += wave_shfl_xor(a, 1); a += wave_shfl_xor(a, 2); a += wave_shfl_xor(a, 4); a += wave_shfl_xor(a, 8);
+    if (o < 12 && kk == 0) pose[n * 12 + o] = 0.01f * (a + b2[o]);
 }
 
 // blocks [0,N): dz1[n,p,c] = relu'(x) * (sum_o w2[o][c] * 0.01*dpose[n][o]) / HW
@@ -177,12 +192,21 @@ __global__ __launch_bounds__(256) void pose_head_bwd_kernel(const float* __restr
         return;
     }
     const int n = blockIdx.x;
-    float dm = 0.f;
-    for (int o = 0; o < 12; ++o) dm = fmaf(w2[o * 256 + c], 0.01f * dpose[n * 12 + o], dm);
-    dm = dm / (float)HW;
-    for (int p = 0; p < HW; ++p) {
-        const size_t i = ((size_t)n * HW + p) * 256 + c;
-        dz1[i] = x[i] > 0.f ? dm : 0.f;
+    const int c4 = c & 63, pl = c >> 6;      // channel quad, pixel lane (16-byte accesses, 4 pixels in flight)
+    float dm[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float v = 0.f;
+        for (int o = 0; o < 12; ++o) v = fmaf(w2[o * 256 + c4 * 4 + k], 0.01f * dpose[n * 12 + o], v);
+        dm[k] = v / (float)HW;
+    }
+    for (int p = pl; p < HW; p += 4) {
+        const size_t i = ((size_t)n * HW + p) * 256 + c4 * 4;
+        const float4 xv = *reinterpret_cast<const float4*>(x + i);
+        float4 g;
+        g.x = xv.x > 0.f ? dm[0] : 0.f; g.y = xv.y > 0.f ? dm[1] : 0.f;
+        g.z = xv.z > 0.f ? dm[2] : 0.f; g.w = xv.w > 0.f ? dm[3] : 0.f;
+        *reinterpret_cast<float4*>(dz1 + i) = g;
     }
 }
 
