@@ -178,53 +178,54 @@ __global__ __launch_bounds__(256) void loss_bwd2_kernel(Pyramid pyr, const unsig
         for (int q = 0; q < 9; ++q) cs[q][e] = need ? coef[(size_t)q * HW + (size_t)yy * W + xx] : 0.f;
     }
     __syncthreads();
-    float dPacc[24];
-#pragma unroll
-    for (int k = 0; k < 24; ++k) dPacc[k] = 0.f;
     const float* Ki = Kinv + (size_t)b * 16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // One pass per source frame: only 12 pose-gradient accumulators and one set of stencil sums are live at
+    // a time (the two-frame version needed 152 VGPRs = 3 waves per SIMD).
 #pragma unroll 1
-    for (int it = 0; it < (LB_TH * LB_TW) / 256; ++it) {
-        const int lp = threadIdx.x + it * 256;
-        const int ly = lp / LB_TW, lx = lp - ly * LB_TW;
-        const int y = y0 + ly, x = x0 + lx;
-        if (y >= H || x >= W) continue;
-        const int pi = y * W + x;
-        // transposed stencil: weights of the 3x3 neighbours incl. the reflection fold (rows/cols 0 and H-1 / W-1
-        // are counted twice for the second / second-to-last row / column)
-        float wy[3] = {1.f, 1.f, 1.f}, wx[3] = {1.f, 1.f, 1.f};
-        if (y == 1) wy[0] = 2.f;
-        if (y == H - 2) wy[2] = 2.f;
-        if (x == 1) wx[0] = 2.f;
-        if (x == W - 2) wx[2] = 2.f;
-        float sA[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}}, sB[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}},
-              sC[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+    for (int fi = 0; fi < 2; ++fi) {
+        const int n = fi * B + b;
+        const float* Pm = P + (size_t)n * 12;
+        const float* src = (fi == 0 ? src_m1 : src_p1) + (size_t)b * 3 * HW;
+        const unsigned char want = (unsigned char)(2 + fi);
+        float dPacc[12];
 #pragma unroll
-        for (int dy = 0; dy < 3; ++dy)
+        for (int k = 0; k < 12; ++k) dPacc[k] = 0.f;
+#pragma unroll 1
+        for (int it = 0; it < (LB_TH * LB_TW) / 256; ++it) {
+            const int lp = threadIdx.x + it * 256;
+            const int ly = lp / LB_TW, lx = lp - ly * LB_TW;
+            const int y = y0 + ly, x = x0 + lx;
+            if (y >= H || x >= W) continue;
+            const int pi = y * W + x;
+            // transposed stencil: weights of the 3x3 neighbours incl. the reflection fold (rows/cols 0 and H-1 /
+            // W-1 are counted twice for the second / second-to-last row / column); branch-free: neighbours that
+            // selected the other frame (or none) enter with weight 0
+            float wy[3] = {1.f, 1.f, 1.f}, wx[3] = {1.f, 1.f, 1.f};
+            if (y == 1) wy[0] = 2.f;
+            if (y == H - 2) wy[2] = 2.f;
+            if (x == 1) wx[0] = 2.f;
+            if (x == W - 2) wx[2] = 2.f;
+            float sA[3] = {0.f, 0.f, 0.f}, sB[3] = {0.f, 0.f, 0.f}, sC[3] = {0.f, 0.f, 0.f};
+#pragma unroll 1
+            for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-            for (int dx = 0; dx < 3; ++dx) {
-                const int e = (ly + dy) * LB_PW + lx + dx;
-                const unsigned char sv = ss[e];
-                if (sv < 2 || sv > 3) continue;
-                const float ww = wy[dy] * wx[dx];
-                const int fi = sv - 2;
+                for (int dx = 0; dx < 3; ++dx) {
+                    const int e = (ly + dy) * LB_PW + lx + dx;
+                    const float ww = ss[e] == want ? (dy == 0 ? wy[0] : dy == 1 ? wy[1] : wy[2]) * wx[dx] : 0.f;
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    sA[fi][c] += ww * cs[c * 3 + 0][e];
-                    sB[fi][c] += ww * cs[c * 3 + 1][e];
-                    sC[fi][c] += ww * cs[c * 3 + 2][e];
+                    for (int c = 0; c < 3; ++c) {
+                        sA[c] = fmaf(ww, cs[c * 3 + 0][e], sA[c]);
+                        sB[c] = fmaf(ww, cs[c * 3 + 1][e], sB[c]);
+                        sC[c] = fmaf(ww, cs[c * 3 + 2][e], sC[c]);
+                    }
                 }
-            }
-        const unsigned char own = ss[(ly + 1) * LB_PW + lx + 1];
-        const float disp = upsample_disp(disp_s + (size_t)b * h * w, h, w, H, W, y, x);
-        const float dep = disp_to_depth_dev(disp, da, db, dmode);
-        const float fx = (float)x, fy = (float)y;
-        float cam[3], X[3];
-        for (int i = 0; i < 3; ++i) { cam[i] = Ki[i * 4 + 0] * fx + Ki[i * 4 + 1] * fy + Ki[i * 4 + 2]; X[i] = dep * cam[i]; }
-        float ddepth = 0.f;
-#pragma unroll
-        for (int fi = 0; fi < 2; ++fi) {
-            const int n = fi * B + b;
-            const float* Pm = P + (size_t)n * 12;
+            const bool own = ss[(ly + 1) * LB_PW + lx + 1] == want;
+            const float disp = upsample_disp(disp_s + (size_t)b * h * w, h, w, H, W, y, x);
+            const float dep = disp_to_depth_dev(disp, da, db, dmode);
+            const float fx = (float)x, fy = (float)y;
+            float cam[3], X[3];
+            for (int i = 0; i < 3; ++i) { cam[i] = Ki[i * 4 + 0] * fx + Ki[i * 4 + 1] * fy + Ki[i * 4 + 2]; X[i] = dep * cam[i]; }
             float p[3];
             for (int i = 0; i < 3; ++i) p[i] = Pm[i * 4 + 0] * X[0] + Pm[i * 4 + 1] * X[1] + Pm[i * 4 + 2] * X[2] + Pm[i * 4 + 3];
             const float den = p[2] + 1e-7f;
@@ -233,14 +234,13 @@ __global__ __launch_bounds__(256) void loss_bwd2_kernel(Pyramid pyr, const unsig
             const float wx1 = s.ix - (float)s.x0, wy1 = s.iy - (float)s.y0;
             const float wx0 = (float)(s.x0 + 1) - s.ix, wy0 = (float)(s.y0 + 1) - s.iy;
             const bool x1ok = s.x0 + 1 < W, y1ok = s.y0 + 1 < H;
-            const float* src = (fi == 0 ? src_m1 : src_p1) + (size_t)b * 3 * HW;
             float gix = 0.f, giy = 0.f;
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 const float xv = warped[((size_t)n * 3 + c) * HW + pi];
                 const float yv = target[((size_t)b * 3 + c) * HW + pi];
-                float g = sA[fi][c] + sB[fi][c] * xv + sC[fi][c] * yv;
-                if (own == 2 + fi) g += (0.15f / 3.f) * (xv > yv ? 1.f : (xv < yv ? -1.f : 0.f));
+                float g = sA[c] + sB[c] * xv + sC[c] * yv;
+                if (own) g += (0.15f / 3.f) * (xv > yv ? 1.f : (xv < yv ? -1.f : 0.f));
                 g *= wq;
                 const float* pl = src + (size_t)c * HW;
                 const float nw = pl[s.y0 * W + s.x0];
@@ -256,19 +256,22 @@ __global__ __launch_bounds__(256) void loss_bwd2_kernel(Pyramid pyr, const unsig
             dp[0] = du * inv_den; dp[1] = dv * inv_den; dp[2] = -(du * u + dv * v) * inv_den;
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                dPacc[fi * 12 + i * 4 + 0] += dp[i] * X[0]; dPacc[fi * 12 + i * 4 + 1] += dp[i] * X[1];
-                dPacc[fi * 12 + i * 4 + 2] += dp[i] * X[2]; dPacc[fi * 12 + i * 4 + 3] += dp[i];
+                dPacc[i * 4 + 0] += dp[i] * X[0]; dPacc[i * 4 + 1] += dp[i] * X[1];
+                dPacc[i * 4 + 2] += dp[i] * X[2]; dPacc[i * 4 + 3] += dp[i];
             }
+            float ddepth = 0.f;
             for (int j = 0; j < 3; ++j)
                 ddepth += (Pm[0 * 4 + j] * dp[0] + Pm[1 * 4 + j] * dp[1] + Pm[2 * 4 + j] * dp[2]) * cam[j];
+            const float dd = (dmode == 2) ? -db * dep * dep * ddepth : -dep / disp * ddepth;
+            // frame 0 writes, frame 1 adds (same thread, same address: ordered)
+            float* o = ddisp_up + (size_t)b * HW + pi;
+            *o = fi == 0 ? dd : *o + dd;
         }
-        ddisp_up[(size_t)b * HW + pi] = (dmode == 2) ? -db * dep * dep * ddepth : -dep / disp * ddepth;
-    }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-    for (int k = 0; k < 24; ++k) {
-        const float s = wave_sum(dPacc[k]);
-        if (lane == 0) red[wave][k] = s;
+        for (int k = 0; k < 12; ++k) {
+            const float s = wave_sum(dPacc[k]);
+            if (lane == 0) red[wave][fi * 12 + k] = s;
+        }
     }
     __syncthreads();
     if (threadIdx.x < 24)
