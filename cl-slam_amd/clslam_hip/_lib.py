@@ -47,7 +47,7 @@ _SIGNATURES = {
     'clslam_conv2d_pick_config': [C.POINTER(ConvDesc)],
     'clslam_weight_transpose': [fptr, fptr, i32, i32, i32, i32, C.c_void_p],
     'clslam_fold_blocks': [i32, i32, i32, i32, i32],
-    'clslam_fold_act_grad': [fptr, fptr, fptr, fptr, i32, i32, i32, i32, i32, i32, i32, i32, C.c_void_p],
+    'clslam_fold_act_grad': [fptr, fptr, fptr, fptr, i32, i32, i32, i32, i32, i32, i32, i32, fptr, fptr, C.c_void_p],
     'clslam_wgrad_splits': [C.POINTER(ConvDesc), i32],
     'clslam_conv_wgrad': [C.POINTER(ConvDesc), fptr, fptr, i32, C.c_void_p],
     'clslam_wgrad_patch_supported': [C.POINTER(ConvDesc)],

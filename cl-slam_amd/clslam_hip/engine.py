@@ -637,13 +637,10 @@ class Engine:
         dxp_in = None  # padded-domain gradient w.r.t. x[i,1] coming from upconv_{i-1}_0
         for i in range(5):
             hi, wi, ci = H >> i, W >> i, NUM_CH_DEC[i]
+            wd = None
             if i <= 3:
+                # the dispconv head's data gradient is folded in by fold_act_grad below (no separate pass over dxp)
                 wd, _ = self._wb(f'depth_decoder/dispconv_{i}.conv', 1, ci, 9)
-                if dxp_in is None:
-                    dxp_in = t.dxp[0][:B * (hi + 2) * (wi + 2) * ci].view(B, hi + 2, wi + 2, ci)
-                    ops.dispconv_bwd_data(t.dz_disp[i], wd.view(9, ci), dxp_in, ci, accumulate=False)
-                else:
-                    ops.dispconv_bwd_data(t.dz_disp[i], wd.view(9, ci), dxp_in, ci, accumulate=True)
 
                 def disp_wgrad(i=i, hi=hi, wi=wi, ci=ci):   # dispconv weight + bias gradient partials
                     if i not in t.disp_part:
@@ -655,7 +652,8 @@ class Engine:
                 on_wg(disp_wgrad)
             nb1 = ops.fold_blocks(B, hi, wi, ci, False)
             ops.fold_act_grad(dxp_in, ws.x[i, 1], t.dz[i, 1], h=hi, w=wi, ch=ci, border=1, pool=False, act=ACT_ELU,
-                              bias_partial=t.bias_part[i, 1])
+                              bias_partial=t.bias_part[i, 1], disp_dz=t.dz_disp[i] if wd is not None else None,
+                              disp_w=wd.view(9, ci) if wd is not None else None)
             # upconv_i_1: input = cat(up(x[i,0]), feats[i-1])
             skip = feats[i - 1] if i > 0 else None
             cin1 = ci + (NUM_CH_ENC[i - 1] if i > 0 else 0)

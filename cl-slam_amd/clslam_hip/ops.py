@@ -109,10 +109,11 @@ def fold_blocks(batch, h, w, ch, pool) -> int:
     return _lib.get_lib().cdll.clslam_fold_blocks(batch, h, w, ch, int(pool))
 
 
-def fold_act_grad(dxp, yout, dz, *, h, w, ch, border, pool, act, bias_partial=None):
-    B = dxp.shape[0]
-    _lib.get_lib().call('clslam_fold_act_grad', _p(dxp), _p(yout), _p(dz), _p(bias_partial), B, h, w, ch, dxp.shape[3],
-                        border, int(pool), act, _stream(dz))
+def fold_act_grad(dxp, yout, dz, *, h, w, ch, border, pool, act, bias_partial=None, disp_dz=None, disp_w=None):
+    """disp_dz (B,h,w) + disp_w (9,ch): also add the dispconv head's data gradient (dxp may be None then)."""
+    B = dz.shape[0]
+    _lib.get_lib().call('clslam_fold_act_grad', _p(dxp), _p(yout), _p(dz), _p(bias_partial), B, h, w, ch,
+                        ch if dxp is None else dxp.shape[3], border, int(pool), act, _p(disp_dz), _p(disp_w), _stream(dz))
     return dz
 
 

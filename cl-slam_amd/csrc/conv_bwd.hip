@@ -29,9 +29,14 @@ __global__ void weight_transpose_kernel(const float* __restrict__ w, float* __re
 
 // ------------------------------------------------------------------------------------------------
 // dz[b,y,x,c] = act'(yout[b,y,x,c]) * sum_{(Y,X) in footprint(y,x)} sum_{P -> (Y,X)} dxp[b,P,c]
+// disp_dz / disp_w (optional, pool == 0, e == 1): the dispconv head hanging off the same activation
+// (depth_decoder.py:67-69).  Its data gradient on the padded domain, sum_k disp_dz[P-2+k] * disp_w[flip k][c],
+// is evaluated here per folded position instead of a separate read-modify-write pass over dxp
+// (clslam_dispconv_bwd_data); dxp may then be NULL (scale 0: no upconv feeds on this activation's padded grad).
 __global__ __launch_bounds__(256) void fold_act_grad_kernel(const float* __restrict__ dxp, const float* __restrict__ yout,
                                                             float* __restrict__ dz, float* __restrict__ bias_partial, int B,
-                                                            int H, int W, int C, int e, int pool, int act, int Cp) {
+                                                            int H, int W, int C, int e, int pool, int act, int Cp,
+                                                            const float* __restrict__ disp_dz, const float* __restrict__ disp_w) {
     // bias_partial (optional): [gridDim.x][C] per-block column sums of dz = the conv's bias gradient
     // partials (C/4 divides 256 and the grid stride, so a thread keeps one channel quad throughout).
     __shared__ float4 bred[256];
@@ -43,6 +48,12 @@ __global__ __launch_bounds__(256) void fold_act_grad_kernel(const float* __restr
     const int Hp = H + 2 * e, Wp = W + 2 * e;
     // 32-bit index arithmetic (the host checks total < 2^31): 64-bit div/mod chains cost more than the loads
     const int total = B * Ho * Wo * C4;
+    // C/4 divides 256 and the grid stride: a thread keeps one channel quad, so its 9 head weights stay in registers
+    float4 dw[9];
+    if (disp_dz) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) dw[t] = *reinterpret_cast<const float4*>(disp_w + t * C + (threadIdx.x % C4) * 4);
+    }
     for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
         const int c4 = i % C4;
         const int pix = i / C4;
@@ -67,9 +78,27 @@ __global__ __launch_bounds__(256) void fold_act_grad_kernel(const float* __restr
                 }
                 for (int a = 0; a < npy; ++a)
                     for (int q = 0; q < npx; ++q) {
-                        const float4 v = *reinterpret_cast<const float4*>(
-                            dxp + ((size_t)(b * Hp + py[a]) * Wp + px[q]) * Cp + c4 * 4);
-                        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+                        if (dxp) {
+                            const float4 v = *reinterpret_cast<const float4*>(
+                                dxp + ((size_t)(b * Hp + py[a]) * Wp + px[q]) * Cp + c4 * 4);
+                            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+                        }
+                        if (disp_dz) {
+#pragma unroll
+                            for (int ky = 0; ky < 3; ++ky) {
+                                const int yy = py[a] - 2 + ky;
+                                if (yy < 0 || yy >= H) continue;
+#pragma unroll
+                                for (int kx = 0; kx < 3; ++kx) {
+                                    const int xx = px[q] - 2 + kx;
+                                    if (xx < 0 || xx >= W) continue;
+                                    const float g = disp_dz[((size_t)b * H + yy) * W + xx];
+                                    const float4 k = dw[(2 - ky) * 3 + (2 - kx)];
+                                    acc.x = fmaf(g, k.x, acc.x); acc.y = fmaf(g, k.y, acc.y);
+                                    acc.z = fmaf(g, k.z, acc.z); acc.w = fmaf(g, k.w, acc.w);
+                                }
+                            }
+                        }
                     }
             }
         }
@@ -403,8 +432,11 @@ extern "C" int clslam_fold_blocks(int batch, int h, int w, int ch, int pool) {
 }
 
 extern "C" int clslam_fold_act_grad(const float* dxp, const float* yout, float* dz, float* bias_partial, int batch, int h,
-                                    int w, int ch, int ch_stride, int border, int pool, int act, void* stream) {
-    CLSLAM_REQUIRE(dxp && dz && ch % 4 == 0 && ch_stride % 4 == 0 && ch <= ch_stride, "fold_act_grad: bad args");
+                                    int w, int ch, int ch_stride, int border, int pool, int act, const float* disp_dz,
+                                    const float* disp_w, void* stream) {
+    CLSLAM_REQUIRE((dxp || disp_dz) && dz && ch % 4 == 0 && ch_stride % 4 == 0 && ch <= ch_stride, "fold_act_grad: bad args");
+    CLSLAM_REQUIRE(!disp_dz || (disp_w && !pool && border == 1 && 256 % (ch / 4) == 0),
+                   "fold_act_grad: the fused dispconv gradient needs disp_w, border 1, no pooling and ch/4 dividing 256");
     CLSLAM_REQUIRE(border == 0 || border == 1, "fold_act_grad: border must be 0/1");
     CLSLAM_REQUIRE(!pool || (h % 2 == 0 && w % 2 == 0), "fold_act_grad: pooling needs even dims");
     const size_t total = (size_t)batch * (pool ? h / 2 : h) * (pool ? w / 2 : w) * (ch / 4);
@@ -413,7 +445,7 @@ extern "C" int clslam_fold_act_grad(const float* dxp, const float* yout, float* 
     CLSLAM_REQUIRE(total < ((size_t)1 << 31) - 256 * 4096, "fold_act_grad: tensor too large for 32-bit indexing");
     const int blocks = clslam_fold_blocks(batch, h, w, ch, pool);
     hipLaunchKernelGGL(fold_act_grad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dxp, yout, dz, bias_partial, batch,
-                       h, w, ch, border, pool, act, ch_stride);
+                       h, w, ch, border, pool, act, ch_stride, disp_dz, disp_w);
     return check_launch("fold_act_grad");
 }
 

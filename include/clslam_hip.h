@@ -99,8 +99,12 @@ int clslam_weight_transpose(const float* w, float* wt, int ch_out, int taps, int
 /* bias_partial (optional) receives [clslam_fold_blocks(...)][ch] per-block column sums of dz, i.e.
  * the bias-gradient partials of the conv that produced yout (reduce with clslam_reduce_partials). */
 int clslam_fold_blocks(int batch, int h, int w, int ch, int pool);
+/* disp_dz (B,h,w) / disp_w (9,ch), optional (pool = 0, border = 1): additionally adds the data gradient of
+ * the dispconv head that reads the same activation (what clslam_dispconv_bwd_data would accumulate into
+ * dxp), evaluated per folded position; dxp may then be NULL.                                        */
 int clslam_fold_act_grad(const float* dxp, const float* yout, float* dz, float* bias_partial, int batch, int h, int w,
-                         int ch, int ch_stride, int border, int pool, int act, void* stream);
+                         int ch, int ch_stride, int border, int pool, int act, const float* disp_dz, const float* disp_w,
+                         void* stream);
 /* Weight gradient as an MFMA GEMM reducing over pixels; desc = the forward conv's descriptor. */
 int clslam_wgrad_splits(const clslam_conv_desc* desc, int target_blocks);
 int clslam_conv_wgrad(const clslam_conv_desc* desc, const float* dz, float* partial, int splits, void* stream);

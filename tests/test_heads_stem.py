@@ -56,6 +56,13 @@ def test_dispconv_fwd_bwd(backend, B, H, W, C):
     dx = torch.empty(B, H, W, C, device=dev)
     ops.fold_act_grad(dxp, None, dx, h=H, w=W, ch=C, border=1, pool=False, act=0)
     assert rel_err(dx.cpu(), 2 * x.grad) < 2e-5
+    # the same gradient fused into the fold (what the engine uses): alone, and on top of an upstream dxp
+    dx2 = torch.full((B, H, W, C), float('nan'), device=dev)
+    ops.fold_act_grad(None, None, dx2, h=H, w=W, ch=C, border=1, pool=False, act=0, disp_dz=dz.to(dev), disp_w=wd)
+    assert rel_err(dx2.cpu(), x.grad) < 2e-5
+    dx3 = torch.empty(B, H, W, C, device=dev)
+    ops.fold_act_grad(dxp, None, dx3, h=H, w=W, ch=C, border=1, pool=False, act=0, disp_dz=dz.to(dev), disp_w=wd)
+    assert rel_err(dx3.cpu(), 3 * x.grad) < 2e-5
     nb = ops.dispconv_wgrad_blocks(B * H * W)
     n = 9 * C + 1
     part = torch.full((nb * n,), float('nan'), device=dev)

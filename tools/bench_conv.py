@@ -10,6 +10,8 @@ sys.path.insert(0, str(Path(__file__).resolve().parents[1] / 'cl-slam_amd'))
 from clslam_hip import ops  # noqa: E402
 
 dev = torch.device('cuda:0')
+SPLITK = bool(int(__import__('os').environ.get('CLSLAM_SPLITK', '0') or 0))
+WGRAD = __import__('os').environ.get('BENCH_WGRAD', '1') != '0'
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 H, W = 192, 640
 # name, B mult, Hi, Wi, Ca, Cb, Cout, k, stride, reflect, ups
@@ -60,18 +62,22 @@ for name, bm, Hi, Wi, Ca, Cb, Cout, k, stride, refl, ups in LAYERS:
     out = torch.empty(Bn, Ho, Wo, Cout, device=dev)
     flops = 2.0 * Bn * Ho * Wo * Cout * k * k * (Ca + Cb)
     line = f'{name:32s} M={Bn*Ho*Wo:7d} {flops/1e9:7.2f} GF |'
-    cfgs = [-1] + ([24, 25] if (stride == 1 and k == 3 and (Ca + Cb) % 32 == 0 and Hi <= 24) else [])
+    cfgs = [-1] + ([int(c) for c in sys.argv[2].split(',')] if len(sys.argv) > 2 else [])
     wsk = torch.zeros(32 << 20, dtype=torch.uint8, device=dev)
     for cfg in cfgs:
         try:
             t = timeit(lambda: ops.conv2d(xa, w, out, src_b=xb, ksize=k, stride=stride, pad_mode=refl, upsample_a=bool(ups),
                                           act=1, config=cfg))
             line += f' c{cfg}:{flops/t/1e12:6.1f}'
-            t = timeit(lambda: ops.conv2d(xa, w, out, src_b=xb, ksize=k, stride=stride, pad_mode=refl, upsample_a=bool(ups),
-                                          act=1, config=cfg, workspace=wsk))
-            line += f' splitK:{flops/t/1e12:6.1f}'
+            if cfg == -1 and SPLITK:
+                t = timeit(lambda: ops.conv2d(xa, w, out, src_b=xb, ksize=k, stride=stride, pad_mode=refl, upsample_a=bool(ups),
+                                              act=1, config=cfg, workspace=wsk))
+                line += f' splitK:{flops/t/1e12:6.1f}'
         except Exception:
             line += f' c{cfg}:   -  '
+    if not WGRAD:
+        print(line, flush=True)
+        continue
     # wgrad
     dz = torch.randn(Bn, Ho, Wo, Cout, device=dev)
     desc = ops.conv_desc(xa, (Bn, Ho, Wo, Cout), src_b=xb, ksize=k, stride=stride, pad_mode=refl, upsample_a=bool(ups))

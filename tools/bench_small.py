@@ -46,7 +46,7 @@ for i in range(4):
     dxp = t.dxp[0][:B * (hi + 2) * (wi + 2) * ci].view(B, hi + 2, wi + 2, ci)
     timeit(f'dispconv_bwd_data s{i}', lambda: ops.dispconv_bwd_data(t.dz_disp[i], wd.view(9, ci), dxp, ci, accumulate=True))
     timeit(f'dispconv_wgrad s{i}', lambda: ops.dispconv_wgrad(t.dz_disp[i], ws.x[i, 1], t.disp_part[i]))
-    timeit(f'fold_act_grad s{i} nopool', lambda: ops.fold_act_grad(dxp, ws.x[i, 1], t.dz[i, 1], h=hi, w=wi, ch=ci, border=1, pool=False,
+    timeit(f"fold_act_grad s{i} nopool+disp", lambda: ops.fold_act_grad(dxp, ws.x[i, 1], t.dz[i, 1], h=hi, w=wi, ch=ci, border=1, pool=False, disp_dz=t.dz_disp[i], disp_w=wd.view(9, ci),
                                                                    act=ACT_ELU, bias_partial=t.bias_part[i, 1]))
     timeit(f'fold_act_grad s{i} pool', lambda: ops.fold_act_grad(dxp, ws.x[i, 0], t.dz[i, 0], h=hi, w=wi, ch=ci, border=1, pool=True,
                                                                  act=ACT_ELU, bias_partial=t.bias_part[i, 0]))
