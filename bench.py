@@ -165,17 +165,18 @@ def main():
             a[2] += 1
         ops.PROFILE = None
         p.engine.use_side_stream = True
+        # kernel names as rocprofv3 prints them (template arguments TH, TW, BN, BK, MF, WGM, RUN, LDPAD, S, SK)
+        patch = {10: '8, 16, 64, 16, 32, 2, false, 4, 1', 11: '8, 16, 32, 16, 32, 4, false, 4, 1', 12: '8, 16, 16, 16, 16, 4, false, 4, 1',
+                 13: '4, 16, 64, 16, 32, 2, false, 4, 1', 14: '8, 16, 16, 32, 16, 4, false, 4, 1', 15: '16, 16, 16, 16, 16, 4, false, 4, 1',
+                 16: '8, 16, 32, 16, 16, 4, false, 4, 1', 17: '4, 16, 16, 16, 16, 4, false, 4, 1', 18: '4, 16, 16, 16, 16, 4, true, 4, 1',
+                 19: '8, 16, 16, 16, 16, 4, true, 4, 1', 20: '8, 16, 16, 16, 16, 4, false, 8, 1', 21: '4, 16, 16, 16, 16, 4, false, 8, 1',
+                 22: '4, 16, 16, 16, 16, 4, true, 8, 1', 23: '4, 16, 16, 16, 16, 4, false, 8, 2', 24: '4, 16, 16, 32, 16, 4, true, 8, 1',
+                 25: '4, 16, 16, 32, 16, 4, false, 8, 1'}
         names = {0: 'conv_igemm_kernel<128, 64, 32, 32, 2>', 1: 'conv_igemm_kernel<64, 64, 32, 32, 2>',
                  2: 'conv_igemm_kernel<32, 32, 32, 16, 2>', 3: 'conv_igemm_kernel<64, 32, 32, 16, 2>',
                  4: 'conv_igemm_kernel<128, 16, 16, 16, 4>', 5: 'conv_igemm_kernel<64, 32, 16, 16, 2>',
-                 6: 'conv_igemm_kernel<128, 16, 32, 16, 4>', 10: 'conv3x3_patch_kernel<8, 16, 64, 16, 32, 2>',
-                 11: 'conv3x3_patch_kernel<8, 16, 32, 16, 32, 4>', 12: 'conv3x3_patch_kernel<8, 16, 16, 16, 16, 4, false, 4, 1>',
-                 13: 'conv3x3_patch_kernel<4, 16, 64, 16, 32, 2>', 14: 'conv3x3_patch_kernel<8, 16, 16, 32, 16, 4>',
-                 15: 'conv3x3_patch_kernel<16, 16, 16, 16, 16, 4>', 16: 'conv3x3_patch_kernel<8, 16, 32, 16, 16, 4>',
-                 17: 'conv3x3_patch_kernel<4, 16, 16, 16, 16, 4, false, 4, 1>', 18: 'conv3x3_patch_kernel<4, 16, 16, 16, 16, 4, true, 4, 1>',
-                 19: 'conv3x3_patch_kernel<8, 16, 16, 16, 16, 4, true, 4, 1>', 20: 'conv3x3_patch_kernel<8, 16, 16, 16, 16, 4, false, 8, 1>',
-                 21: 'conv3x3_patch_kernel<4, 16, 16, 16, 16, 4, false, 8, 1>', 22: 'conv3x3_patch_kernel<4, 16, 16, 16, 16, 4, true, 8, 1>',
-                 23: 'conv3x3_patch_kernel<4, 16, 16, 16, 16, 4, false, 8, 2>'}
+                 6: 'conv_igemm_kernel<128, 16, 32, 16, 4>'}
+        names.update({k: f'conv3x3_patch_kernel<{v}, false>' for k, v in patch.items()})
         (kind, cfg), (fl, tt, cnt) = max(agg.items(), key=lambda kv: kv[1][1])
         all_fl = sum(a[0] for a in agg.values())
         all_t = sum(a[1] for a in agg.values())

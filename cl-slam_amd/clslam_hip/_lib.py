@@ -93,7 +93,8 @@ _SIGNATURES = {
     'clslam_photo_grad': [fptr, fptr, fptr, fptr, fptr, fptr, i32, i32, i32, C.c_void_p],
     'clslam_mbv3_stem': [fptr, fptr, fptr, fptr, fptr, i32, i32, i32, C.c_void_p],
     'clslam_dwconv': [fptr, fptr, fptr, fptr, fptr, i32, i32, i32, i32, i32, i32, i32, C.c_void_p],
-    'clslam_global_avgpool': [fptr, fptr, i32, i32, i32, C.c_void_p],
+    'clslam_avgpool_chunks': [i32],
+    'clslam_global_avgpool': [fptr, fptr, fptr, i32, i32, i32, C.c_void_p],
     'clslam_se_gate': [fptr, fptr, fptr, fptr, fptr, fptr, i32, i32, i32, C.c_void_p],
     'clslam_channel_scale': [fptr, fptr, i32, i32, i32, C.c_void_p],
     'clslam_adam_step': [fptr, fptr, fptr, fptr, C.c_size_t, C.c_double, C.c_double, C.c_double, C.c_double, i32, C.c_float,

@@ -3,6 +3,7 @@ loop_closure_detection/encoder.py:13-33).  Weights come in torchvision's state-d
 (``features.N...``); eval BatchNorm (eps 1e-3) is folded to scale/shift, channel counts are
 zero-padded to multiples of 16 so the 1x1 convolutions run on the MFMA conv kernel.
 """
+import os
 from typing import Dict, List
 
 import torch
@@ -95,6 +96,7 @@ class MobileNetV3SmallHIP:
             self.blocks.append(blk)
         self.head = pw('features.12', 96, 576)
         self._bufs = {}
+        self._graphs = {}
 
     def _buf(self, key, *shape):
         t = self._bufs.get((key,) + shape)
@@ -104,8 +106,34 @@ class MobileNetV3SmallHIP:
         return t
 
     def __call__(self, image: torch.Tensor) -> torch.Tensor:
-        """image (B,3,H,W) in [0,1] (un-normalised, like the reference passes it) -> (B,576)."""
+        """image (B,3,H,W) in [0,1] (un-normalised, like the reference passes it) -> (B,576).
+
+        On the GPU the 52 launches of a forward are replayed as one hipGraph per input shape (B=1 per frame:
+        the eager forward is launch-latency-bound, 0.78 ms at 192x640 vs the graph replay); CLSLAM_HIPGRAPH=0
+        disables it."""
         x = image.to(self.device, torch.float32).contiguous()
+        if self.device.type != 'cuda' or os.environ.get('CLSLAM_HIPGRAPH', 'auto') == '0':
+            return self._forward(x)
+        st = self._graphs.get(tuple(x.shape))
+        if st is None:
+            st = {'x': x.clone()}
+            cur = torch.cuda.current_stream(self.device)
+            warm = torch.cuda.Stream(device=self.device)
+            warm.wait_stream(cur)
+            with torch.cuda.stream(warm):        # eager warm-up allocates every activation buffer
+                self._forward(st['x'])
+            cur.wait_stream(warm)
+            torch.cuda.synchronize(self.device)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                st['out'] = self._forward(st['x'])
+            st['graph'] = g
+            self._graphs[tuple(x.shape)] = st
+        st['x'].copy_(x, non_blocking=True)
+        st['graph'].replay()
+        return st['out'].clone()
+
+    def _forward(self, x: torch.Tensor) -> torch.Tensor:
         B, _, H, W = x.shape
         h, w = (H - 1) // 2 + 1, (W - 1) // 2 + 1
         cur = self._buf('stem', B, h, w, 16)
@@ -128,7 +156,7 @@ class MobileNetV3SmallHIP:
                 w1, b1, wv2, b2 = blk['se']
                 pool = self._buf(f'p{bi}', B, ep)
                 gate = self._buf(f'g{bi}', B, ep)
-                ops.global_avgpool(cur, pool)
+                ops.global_avgpool(cur, pool, self._buf(f'pp{bi}', B * ops.avgpool_chunks(h * w) * ep))
                 ops.se_gate(pool, w1, b1, wv2, b2, gate)
                 ops.channel_scale(cur, gate)
             wgt, s, t = blk['project']
@@ -139,5 +167,5 @@ class MobileNetV3SmallHIP:
         y = self._buf('head', B, h, w, 576)
         ops.conv2d(cur, wgt, y, scale=s, shift=t, ksize=1, pad=0, act=ACT_HSWISH)
         feat = torch.empty(B, 576, device=self.device)
-        ops.global_avgpool(y, feat)
+        ops.global_avgpool(y, feat, self._buf('pph', B * ops.avgpool_chunks(h * w) * 576))
         return feat

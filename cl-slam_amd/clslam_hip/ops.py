@@ -323,9 +323,14 @@ def dwconv(x, weight, scale, shift, out, ksize, stride, act):
     return out
 
 
-def global_avgpool(x, out):
+def avgpool_chunks(hw: int) -> int:
+    return _lib.get_lib().cdll.clslam_avgpool_chunks(hw)
+
+
+def global_avgpool(x, out, partial=None):
+    """partial: optional (B * avgpool_chunks(HW) * C) scratch -> two-stage reduction over pixel chunks."""
     B, Cc = x.shape[0], x.shape[-1]
-    _lib.get_lib().call('clslam_global_avgpool', _p(x), _p(out), B, x.numel() // (B * Cc), Cc, _stream(out))
+    _lib.get_lib().call('clslam_global_avgpool', _p(x), _p(out), _p(partial), B, x.numel() // (B * Cc), Cc, _stream(out))
     return out
 
 

@@ -78,15 +78,19 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ x
     }
 }
 
-// grid (ceil(C/64), B): 16 channel-quads x 16 pixel lanes per block
-__global__ __launch_bounds__(256) void global_avgpool_kernel(const float* __restrict__ x, float* __restrict__ out, int HW, int C) {
+// Stage 1, grid (ceil(C/64), B, chunks): 16 channel-quads x 16 pixel lanes per block over one pixel chunk;
+// writes the chunk sum to partial[b][chunk][C] (or, chunks == 1, the mean straight to out).  One block per
+// (sample, 64 channels) walking all H*W pixels was a 40-us chain of dependent-latency loads at B = 1.
+__global__ __launch_bounds__(256) void global_avgpool_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                             float* __restrict__ partial, int HW, int C, int chunk_px) {
     __shared__ float4 red[256];
-    const int b = blockIdx.y;
+    const int b = blockIdx.y, ch = blockIdx.z, nch = gridDim.z;
     const int q = threadIdx.x % 16, pl = threadIdx.x / 16;
     const int c4 = blockIdx.x * 16 + q;
+    const int p0 = ch * chunk_px, p1 = min(HW, p0 + chunk_px);
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     if (c4 * 4 < C)
-        for (int p = pl; p < HW; p += 16) {
+        for (int p = p0 + pl; p < p1; p += 16) {
             const float4 v = *reinterpret_cast<const float4*>(x + ((size_t)b * HW + p) * C + c4 * 4);
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
@@ -95,30 +99,51 @@ __global__ __launch_bounds__(256) void global_avgpool_kernel(const float* __rest
     if (pl == 0 && c4 * 4 < C) {
         float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int k = 0; k < 16; ++k) { const float4 v = red[k * 16 + q]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
-        const float inv = 1.f / (float)HW;
-        t.x *= inv; t.y *= inv; t.z *= inv; t.w *= inv;
-        *reinterpret_cast<float4*>(out + (size_t)b * C + c4 * 4) = t;
+        if (nch == 1) {
+            const float inv = 1.f / (float)HW;
+            t.x *= inv; t.y *= inv; t.z *= inv; t.w *= inv;
+            *reinterpret_cast<float4*>(out + (size_t)b * C + c4 * 4) = t;
+        } else {
+            *reinterpret_cast<float4*>(partial + ((size_t)b * nch + ch) * C + c4 * 4) = t;
+        }
     }
 }
 
-// one block per sample: hidden = relu(w1*pool+b1) (S <= 256), gate = hardsigmoid(w2*hidden+b2)
+// Stage 2: out[b][c] = (sum over chunks, in order) / HW
+__global__ __launch_bounds__(256) void avgpool_finish_kernel(const float* __restrict__ partial, float* __restrict__ out, int B,
+                                                             int C, int nch, int HW) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * C) return;
+    const int b = i / C, c = i - b * C;
+    float s = 0.f;
+    for (int k = 0; k < nch; ++k) s += partial[((size_t)b * nch + k) * C + c];
+    out[i] = s / (float)HW;
+}
+
+// grid (ceil(C/64), B).  Every block recomputes hidden = relu(w1*pool+b1) (S <= 256; 16 lanes per hidden unit,
+// shuffle-reduced) and then produces 64 gate channels, gate = hardsigmoid(w2*hidden+b2), 4 lanes per channel.
 __global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ pool, const float* __restrict__ w1,
                                                       const float* __restrict__ b1, const float* __restrict__ w2,
                                                       const float* __restrict__ b2, float* __restrict__ gate, int C, int S) {
     __shared__ float hid[256];
-    const int b = blockIdx.x;
+    const int b = blockIdx.y;
     const float* pv = pool + (size_t)b * C;
-    for (int s = threadIdx.x; s < S; s += 256) {
-        float a = b1[s];
-        for (int c = 0; c < C; ++c) a = fmaf(w1[(size_t)s * C + c], pv[c], a);
-        hid[s] = a > 0.f ? a : 0.f;
+    const int sl = threadIdx.x >> 4, cl = threadIdx.x & 15;
+    for (int s0 = 0; s0 < S; s0 += 16) {          // uniform trip count: the shuffles need every lane
+        const int s = s0 + sl;
+        float a = 0.f;
+        if (s < S)
+            for (int c = cl; c < C; c += 16) a = fmaf(w1[(size_t)s * C + c], pv[c], a);
+        a += wave_shfl_xor(a, 1); a += wave_shfl_xor(a, 2); a += wave_shfl_xor(a, 4); a += wave_shfl_xor(a, 8);
+        if (s < S && cl == 0) { a += b1[s]; hid[s] = a > 0.f ? a : 0.f; }
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < C; c += 256) {
-        float a = b2[c];
-        for (int s = 0; s < S; ++s) a = fmaf(w2[(size_t)c * S + s], hid[s], a);
-        gate[(size_t)b * C + c] = apply_act(a, CLSLAM_ACT_HSIGMOID);
-    }
+    const int c = blockIdx.x * 64 + (threadIdx.x >> 2), kl = threadIdx.x & 3;
+    float a = 0.f;
+    if (c < C)
+        for (int s = kl; s < S; s += 4) a = fmaf(w2[(size_t)c * S + s], hid[s], a);
+    a += wave_shfl_xor(a, 1); a += wave_shfl_xor(a, 2);
+    if (c < C && kl == 0) gate[(size_t)b * C + c] = apply_act(a + b2[c], CLSLAM_ACT_HSIGMOID);
 }
 
 __global__ __launch_bounds__(256) void channel_scale_kernel(float* __restrict__ x, const float* __restrict__ gate, int B,
@@ -165,10 +190,18 @@ extern "C" int clslam_dwconv(const float* x, const float* weight, const float* s
     return check_launch("dwconv");
 }
 
-extern "C" int clslam_global_avgpool(const float* x, float* out, int batch, int hw, int ch, void* stream) {
+// Pixel chunks clslam_global_avgpool splits H*W into when given a partial buffer (batch*chunks*ch floats).
+extern "C" int clslam_avgpool_chunks(int hw) { return std::max(1, std::min(64, hw / 64)); }
+
+extern "C" int clslam_global_avgpool(const float* x, float* out, float* partial, int batch, int hw, int ch, void* stream) {
     CLSLAM_REQUIRE(x && out && ch % 4 == 0 && hw > 0, "global_avgpool: bad args");
     if (!batch) return CLSLAM_OK;
-    hipLaunchKernelGGL(global_avgpool_kernel, dim3(cdiv(ch, 64), batch), dim3(256), 0, (hipStream_t)stream, x, out, hw, ch);
+    const int nch = partial ? clslam_avgpool_chunks(hw) : 1;
+    hipLaunchKernelGGL(global_avgpool_kernel, dim3(cdiv(ch, 64), batch, nch), dim3(256), 0, (hipStream_t)stream, x, out, partial,
+                       hw, ch, cdiv(hw, nch));
+    if (nch > 1)
+        hipLaunchKernelGGL(avgpool_finish_kernel, dim3(cdiv(batch * ch, 256)), dim3(256), 0, (hipStream_t)stream, partial, out,
+                           batch, ch, nch, hw);
     return check_launch("global_avgpool");
 }
 
@@ -176,7 +209,8 @@ extern "C" int clslam_se_gate(const float* pool, const float* w1, const float* b
                               int batch, int ch, int squeeze, void* stream) {
     CLSLAM_REQUIRE(pool && w1 && b1 && w2 && b2 && gate && squeeze <= 256, "se_gate: bad args");
     if (!batch) return CLSLAM_OK;
-    hipLaunchKernelGGL(se_gate_kernel, dim3(batch), dim3(256), 0, (hipStream_t)stream, pool, w1, b1, w2, b2, gate, ch, squeeze);
+    hipLaunchKernelGGL(se_gate_kernel, dim3(cdiv(ch, 64), batch), dim3(256), 0, (hipStream_t)stream, pool, w1, b1, w2, b2, gate, ch,
+                       squeeze);
     return check_launch("se_gate");
 }
 

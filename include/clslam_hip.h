@@ -270,7 +270,10 @@ int clslam_mbv3_stem(const float* img, const float* weight, const float* scale, 
 int clslam_dwconv(const float* x, const float* weight, const float* scale, const float* shift, float* out, int batch,
                   int h, int w, int ch, int ksize, int stride, int act, void* stream);
 /* out[b][c] = mean over pixels of x[b][p][c]                                                      */
-int clslam_global_avgpool(const float* x, float* out, int batch, int hw, int ch, void* stream);
+/* partial (optional): batch * clslam_avgpool_chunks(hw) * ch floats -- two-stage reduction over pixel chunks
+ * (deterministic order); NULL = one block per (sample, 64 channels).                                  */
+int clslam_avgpool_chunks(int hw);
+int clslam_global_avgpool(const float* x, float* out, float* partial, int batch, int hw, int ch, void* stream);
 /* squeeze-excitation gates: gate[b][c] = hardsigmoid(w2 * relu(w1 * pool[b] + b1) + b2)            */
 int clslam_se_gate(const float* pool, const float* w1, const float* b1, const float* w2, const float* b2, float* gate,
                    int batch, int ch, int squeeze, void* stream);

@@ -51,3 +51,27 @@ def test_feature_encoder_matches_oracle(backend, B, H, W):
     from clslam_hip._lib import ClslamError
     with pytest.raises(ClslamError):
         FeatureEncoder(dev, weights={k: v for k, v in sd.items() if 'features.3.' not in k})
+
+
+@pytest.mark.gpu
+def test_feature_encoder_latency_on_gpu(capsys):
+    """One LCD descriptor per frame (slam.py:180,223): report and bound the latency at both resolutions of
+    BASELINE.json (B=1; launch-latency-bound: 52 kernel launches, 0.28 GFLOP at 192x640)."""
+    import time
+    dev = use_backend('hip')
+    from loop_closure_detection import FeatureEncoder
+    _, sd = _weights()
+    enc = FeatureEncoder(dev, weights=sd)
+    for H, W in ((192, 640), (384, 1280)):
+        img = synth.make_batch(1, H, W, seed=6)['rgb', 1, 0].to(dev)
+        for _ in range(3):
+            enc(img)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            enc(img)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / 20 * 1e3
+        with capsys.disabled():
+            print(f'\n[lcd] MobileNetV3-small features {H}x{W} B=1: {ms:.3f} ms per call')
+        assert ms < 10.0
