@@ -88,6 +88,8 @@ def main():
     ap.add_argument('--height', type=int, default=192)
     ap.add_argument('--width', type=int, default=640)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--backend', default='nccl', help='torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo lets two '
+                    'ranks share one GPU for a functional check of the sharded path)')
     ap.add_argument('--dump-convs', action='store_true', help='per-launch conv timings to stderr')
     args = ap.parse_args()
     H, W, N = args.height, args.width, args.gpus
@@ -97,12 +99,17 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != N:
         raise SystemExit(f'--gpus {N} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {N}')
+    if args.backend != 'nccl':
+        local_rank %= torch.cuda.device_count()      # functional check: ranks may share a GPU
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     dist = None
     if N > 1:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=dev)
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     K = args.replay * N
     B = 1 + K
@@ -145,6 +152,8 @@ def main():
 
     # ---- roofline of the dominant kernel (instrumented extra step, outside the timed region) ------
     roof = None
+    if rank != 0 and N > 1:
+        step(); step()          # the two extra (collective) steps of rank 0's instrumented pass below
     if rank == 0:
         # serial launch order for this pass: with the pose / wgrad side streams active several kernels share
         # the GPU and a launch's own duration is not its kernel's efficiency
