@@ -93,6 +93,10 @@ _SIGNATURES = {
     'clslam_photo_grad': [fptr, fptr, fptr, fptr, fptr, fptr, i32, i32, i32, C.c_void_p],
     'clslam_mbv3_stem': [fptr, fptr, fptr, fptr, fptr, i32, i32, i32, C.c_void_p],
     'clslam_dwconv': [fptr, fptr, fptr, fptr, fptr, i32, i32, i32, i32, i32, i32, i32, C.c_void_p],
+    'clslam_lanczos_ksize': [i32, i32],
+    'clslam_lanczos_plan': [i32, i32, C.c_void_p, C.c_void_p],
+    'clslam_resize_pass_u8': [C.c_void_p, C.c_void_p, fptr, C.c_void_p, C.c_void_p, i32, i32, i32, i32, i32, i32, i32, C.c_void_p],
+    'clslam_u8_to_planar_f32': [C.c_void_p, fptr, i32, i32, i32, i32, C.c_void_p],
     'clslam_avgpool_chunks': [i32],
     'clslam_global_avgpool': [fptr, fptr, fptr, i32, i32, i32, C.c_void_p],
     'clslam_se_gate': [fptr, fptr, fptr, fptr, fptr, fptr, i32, i32, i32, C.c_void_p],

@@ -1,0 +1,150 @@
+// Image-pyramid ingest: the LANCZOS resize + ToTensor of the reference's datasets
+// (datasets/utils.py:62-66 Resize(LANCZOS) per scale, :154-163 every level from the previous one,
+// :213-215 ToTensor) on uint8 images that were uploaded once, instead of PIL on one host thread.
+//
+// torchvision's Resize on a PIL image is PIL.Image.resize(size, LANCZOS) = Pillow's ImagingResample 8-bit
+// path (libImaging/Resample.c; not part of /root/reference, restated in oracle/resize.py): per output
+// index a window of taps with double-precision Lanczos-3 weights normalised to 1, converted to 22-bit
+// fixed point; horizontal pass then vertical pass, int32 accumulation from 1 << 21, (acc >> 22) clipped
+// to [0,255], uint8 intermediate.  The tap plan is computed on the HOST with libm exactly like Pillow
+// (clslam_lanczos_plan); the kernels are integer multiply-accumulates -> results are BIT-EXACT.
+// HBM-bound byte work: 3 B read + 3 B written per pixel per pass (+12 B for the fused float planes).
+#include <cmath>
+#include <vector>
+
+#include "common.h"
+
+namespace clslam {
+
+constexpr int RS_PRECISION_BITS = 32 - 8 - 2;
+
+// One thread per output pixel (all C <= 4 channels).  axis 1: out (B,H,out,C) from in (B,H,in_w,C);
+// axis 0: out (B,out,W,C) from in (B,in_h,W,C).  planar (optional): float (B,C,oh,ow) = out / 255.
+__global__ __launch_bounds__(256) void resize_pass_u8_kernel(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst,
+                                                             float* __restrict__ planar, const int* __restrict__ bounds,
+                                                             const int* __restrict__ coeffs, int ksize, int B, int in_h, int in_w,
+                                                             int C, int out_size, int axis) {
+    const int oh = axis == 0 ? out_size : in_h, ow = axis == 1 ? out_size : in_w;
+    const int total = B * oh * ow;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int x = i % ow, y = (i / ow) % oh, b = i / (ow * oh);
+        const int o = axis == 1 ? x : y;
+        const int first = bounds[2 * o], n = bounds[2 * o + 1];
+        const int* k = coeffs + (size_t)o * ksize;
+        int acc[4] = {1 << (RS_PRECISION_BITS - 1), 1 << (RS_PRECISION_BITS - 1), 1 << (RS_PRECISION_BITS - 1),
+                      1 << (RS_PRECISION_BITS - 1)};
+        const size_t step = axis == 1 ? (size_t)C : (size_t)in_w * C;
+        const unsigned char* p = src + (((size_t)b * in_h + (axis == 1 ? y : first)) * in_w + (axis == 1 ? first : x)) * C;
+        for (int t = 0; t < n; ++t) {
+            const int w = k[t];
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (c < C) acc[c] += (int)p[c] * w;
+            p += step;
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (c >= C) continue;
+            const int v = min(max(acc[c] >> RS_PRECISION_BITS, 0), 255);
+            dst[(((size_t)b * oh + y) * ow + x) * C + c] = (unsigned char)v;
+            if (planar) planar[(((size_t)b * C + c) * oh + y) * ow + x] = (float)v / 255.f;   // ToTensor
+        }
+    }
+}
+
+// ToTensor alone (level 0 when the raw image already has the model's size)
+__global__ __launch_bounds__(256) void u8_to_planar_kernel(const unsigned char* __restrict__ src, float* __restrict__ planar, int B,
+                                                           int H, int W, int C) {
+    const int total = B * H * W;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int x = i % W, y = (i / W) % H, b = i / (W * H);
+        for (int c = 0; c < C; ++c)
+            planar[(((size_t)b * C + c) * H + y) * W + x] = (float)src[(size_t)i * C + c] / 255.f;
+    }
+}
+
+static double sinc_filter(double x) {
+    if (x == 0.0) return 1.0;
+    x = x * M_PI;
+    return sin(x) / x;
+}
+
+static double lanczos_filter(double x) {
+    if (-3.0 <= x && x < 3.0) return sinc_filter(x) * sinc_filter(x / 3);
+    return 0.0;
+}
+
+}  // namespace clslam
+
+using namespace clslam;
+
+// Taps per output index of a LANCZOS resize in_size -> out_size (the row length of the coefficient table).
+extern "C" int clslam_lanczos_ksize(int in_size, int out_size) {
+    if (in_size <= 0 || out_size <= 0) return 0;
+    double filterscale = (double)in_size / out_size;
+    if (filterscale < 1.0) filterscale = 1.0;
+    return (int)ceil(3.0 * filterscale) * 2 + 1;
+}
+
+// HOST function: bounds[out_size][2] = (first tap, tap count), coeffs[out_size][ksize] = 22-bit fixed-point
+// weights, computed in double with libm like Pillow's precompute_coeffs + normalize_coeffs_8bpc.
+extern "C" int clslam_lanczos_plan(int in_size, int out_size, int* bounds, int* coeffs) {
+    CLSLAM_REQUIRE(in_size > 0 && out_size > 0 && bounds && coeffs, "lanczos_plan: bad args");
+    const double scale = (double)in_size / out_size;
+    const double filterscale = scale < 1.0 ? 1.0 : scale;
+    const double support = 3.0 * filterscale;
+    const int ksize = (int)ceil(support) * 2 + 1;
+    const double ss = 1.0 / filterscale;
+    std::vector<double> k(ksize);
+    for (int xx = 0; xx < out_size; ++xx) {
+        const double center = (xx + 0.5) * scale;
+        double ww = 0.0;
+        int xmin = (int)(center - support + 0.5);
+        if (xmin < 0) xmin = 0;
+        int xmax = (int)(center + support + 0.5);
+        if (xmax > in_size) xmax = in_size;
+        xmax -= xmin;
+        for (int x = 0; x < xmax; ++x) {
+            const double w = lanczos_filter((x + xmin - center + 0.5) * ss);
+            k[x] = w;
+            ww += w;
+        }
+        for (int x = 0; x < xmax; ++x)
+            if (ww != 0.0) k[x] /= ww;
+        for (int x = xmax; x < ksize; ++x) k[x] = 0.0;
+        bounds[2 * xx] = xmin;
+        bounds[2 * xx + 1] = xmax;
+        for (int x = 0; x < ksize; ++x) {
+            const double f = k[x] * (1 << RS_PRECISION_BITS);
+            coeffs[(size_t)xx * ksize + x] = k[x] < 0 ? (int)(-0.5 + f) : (int)(0.5 + f);
+        }
+    }
+    return CLSLAM_OK;
+}
+
+// One pass of the separable resize on interleaved uint8 images (device pointers; bounds/coeffs = the plan
+// uploaded by the caller).  axis 1 = horizontal (width in_w -> out_size), axis 0 = vertical (height in_h ->
+// out_size).  planar (optional): additionally writes ToTensor(out) as float (B,C,oh,ow).
+extern "C" int clslam_resize_pass_u8(const unsigned char* src, unsigned char* dst, float* planar, const int* bounds,
+                                     const int* coeffs, int ksize, int batch, int in_h, int in_w, int ch, int out_size, int axis,
+                                     void* stream) {
+    CLSLAM_REQUIRE(src && dst && bounds && coeffs && ksize > 0 && ch >= 1 && ch <= 4 && (axis == 0 || axis == 1) && out_size > 0,
+                   "resize_pass_u8: bad args");
+    const size_t total = (size_t)batch * (axis == 0 ? out_size : in_h) * (axis == 1 ? out_size : in_w);
+    CLSLAM_REQUIRE(total < ((size_t)1 << 31), "resize_pass_u8: image too large for 32-bit indexing");
+    if (!total) return CLSLAM_OK;
+    const unsigned blocks = (unsigned)std::min<size_t>(8192, (total + 255) / 256);
+    hipLaunchKernelGGL(resize_pass_u8_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, dst, planar, bounds, coeffs,
+                       ksize, batch, in_h, in_w, ch, out_size, axis);
+    return check_launch("resize_pass_u8");
+}
+
+extern "C" int clslam_u8_to_planar_f32(const unsigned char* src, float* planar, int batch, int h, int w, int ch, void* stream) {
+    CLSLAM_REQUIRE(src && planar && ch >= 1, "u8_to_planar_f32: bad args");
+    const size_t total = (size_t)batch * h * w;
+    CLSLAM_REQUIRE(total < ((size_t)1 << 31), "u8_to_planar_f32: image too large for 32-bit indexing");
+    if (!total) return CLSLAM_OK;
+    const unsigned blocks = (unsigned)std::min<size_t>(8192, (total + 255) / 256);
+    hipLaunchKernelGGL(u8_to_planar_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, planar, batch, h, w, ch);
+    return check_launch("u8_to_planar_f32");
+}

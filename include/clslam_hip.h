@@ -259,6 +259,21 @@ int clslam_adam_step(float* param, const float* grad, float* exp_avg, float* exp
                      double beta1, double beta2, double eps, int step, float grad_scale, const float* guard, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Image-pyramid ingest: the reference's datasets resize every pyramid level from the
+ * previous one with torchvision.transforms.Resize(LANCZOS) on PIL images (datasets/utils.py:62-66,154-163)
+ * = Pillow's ImagingResample 8-bit path, then ToTensor (datasets/utils.py:213-215).  Bit-exact on uint8.
+ * clslam_lanczos_plan is a HOST function (double precision + libm, as Pillow): bounds[out][2] = (first tap,
+ * tap count), coeffs[out][clslam_lanczos_ksize] 22-bit fixed point.  clslam_resize_pass_u8 runs one
+ * separable pass on interleaved uint8 images (B,in_h,in_w,ch<=4) on the device: axis 1 = width -> out_size,
+ * axis 0 = height -> out_size (Pillow's order: horizontal first); planar != NULL additionally writes
+ * ToTensor(result) as float (B,ch,oh,ow).  clslam_u8_to_planar_f32 is ToTensor alone.                 */
+int clslam_lanczos_ksize(int in_size, int out_size);
+int clslam_lanczos_plan(int in_size, int out_size, int* bounds, int* coeffs);
+int clslam_resize_pass_u8(const unsigned char* src, unsigned char* dst, float* planar, const int* bounds, const int* coeffs,
+                          int ksize, int batch, int in_h, int in_w, int ch, int out_size, int axis, void* stream);
+int clslam_u8_to_planar_f32(const unsigned char* src, float* planar, int batch, int h, int w, int ch, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Loop-closure feature encoder: MobileNetV3-small forward (loop_closure_detection/encoder.py:13-33:
  * torchvision mobilenet_v3_small cut at 'flatten', ImageNet mean/std normalisation).  The 1x1 convs
  * run through clslam_conv2d (channels zero-padded to multiples of 16); these are the other ops.
