@@ -7,7 +7,8 @@ float pyramids of the sample dict, bit-identical to what the reference's dataset
 
 The tap plans (Pillow's double-precision Lanczos-3 weights in 22-bit fixed point) are computed once per size pair
 by the library's host function and kept on the device; the kernels are integer multiply-accumulates.
-Colour jitter (``datasets/utils.py:236-259``, torchvision's PIL enhancers) is not part of this module.
+``color_jitter`` applies the datasets' colour augmentation (``datasets/utils.py:236-259``: torchvision's brightness /
+contrast / saturation / hue adjustments of PIL images in a drawn order) with Pillow's arithmetic, also bit-exact.
 """
 import ctypes as C
 from typing import Dict, Sequence, Tuple
@@ -74,3 +75,22 @@ class ImagePyramid:
             if s in self.scales:
                 out[s] = planar
         return out
+
+
+BRIGHTNESS, CONTRAST, SATURATION, HUE = 0, 1, 2, 3
+
+
+def color_jitter(frames: torch.Tensor, order: Sequence[int], factors: Sequence[float]) -> torch.Tensor:
+    """frames (N,H,W,3) uint8 on the library's device -> jittered copy.  ``order``: op ids in application order (as
+    ``random.shuffle`` left them in get_random_color_jitter), ``factors`` = (brightness, contrast, saturation, hue)."""
+    if frames.dtype != torch.uint8 or frames.dim() != 4 or frames.shape[-1] != 3:
+        raise _lib.ClslamError(f'color_jitter expects (N,H,W,3) uint8 frames, got {tuple(frames.shape)} {frames.dtype}')
+    frames = frames.contiguous()
+    N, H, W, _ = frames.shape
+    out, scratch = torch.empty_like(frames), torch.empty_like(frames)
+    lsum = torch.zeros(N, dtype=torch.int64, device=frames.device)
+    order_c = (C.c_int * max(len(order), 1))(*[int(o) for o in order])
+    factors_c = (C.c_double * 4)(*[float(f) for f in factors])
+    _lib.get_lib().call('clslam_color_jitter_u8', _pa(frames, torch.uint8), _pa(out, torch.uint8), _pa(scratch, torch.uint8),
+                        _pa(lsum, torch.int64), N, H, W, order_c, len(order), factors_c, _stream(frames))
+    return out

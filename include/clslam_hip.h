@@ -272,6 +272,12 @@ int clslam_lanczos_plan(int in_size, int out_size, int* bounds, int* coeffs);
 int clslam_resize_pass_u8(const unsigned char* src, unsigned char* dst, float* planar, const int* bounds, const int* coeffs,
                           int ksize, int batch, int in_h, int in_w, int ch, int out_size, int axis, void* stream);
 int clslam_u8_to_planar_f32(const unsigned char* src, float* planar, int batch, int h, int w, int ch, void* stream);
+/* Colour augmentation of the datasets (datasets/utils.py:236-259: torchvision adjust_brightness / _contrast /
+ * _saturation / _hue on PIL images, in the order drawn by random.shuffle) with Pillow's exact arithmetic, bit-
+ * exact on uint8 RGB (B,h,w,3).  order[n_ops] (0 brightness, 1 contrast, 2 saturation, 3 hue) and factors[4]
+ * (doubles as Python draws them, indexed by op id) are HOST arrays; scratch = second image buffer, lsum = batch uint64 device scratch.  */
+int clslam_color_jitter_u8(const unsigned char* src, unsigned char* dst, unsigned char* scratch, unsigned long long* lsum,
+                           int batch, int h, int w, const int* order, int n_ops, const double* factors, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Loop-closure feature encoder: MobileNetV3-small forward (loop_closure_detection/encoder.py:13-33:
