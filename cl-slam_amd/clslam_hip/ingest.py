@@ -59,7 +59,9 @@ class ImagePyramid:
             lib.call('clslam_u8_to_planar_f32', _pa(src, torch.uint8), _p(planar), N, h, w, Cc, _stream(src))
         return cur
 
-    def __call__(self, frames: torch.Tensor) -> Dict[int, torch.Tensor]:
+    def __call__(self, frames: torch.Tensor, return_u8: bool = False):
+        """-> {scale: (N,C,h,w) float32}; with return_u8 also {scale: (N,h,w,C) uint8} (the reference jitters every
+        level's uint8 image separately, kitti.py:345-347)."""
         if frames.dim() == 3:
             frames = frames.unsqueeze(0)
         if frames.dtype != torch.uint8 or frames.dim() != 4 or frames.shape[-1] not in (1, 3, 4):
@@ -67,6 +69,7 @@ class ImagePyramid:
         frames = frames.contiguous()
         N, Cc = frames.shape[0], frames.shape[-1]
         out: Dict[int, torch.Tensor] = {}
+        out_u8: Dict[int, torch.Tensor] = {}
         cur = frames
         for s in range(max(self.scales) + 1):
             h, w = self.height >> s, self.width >> s
@@ -74,7 +77,17 @@ class ImagePyramid:
             cur = self._resize(cur, h, w, planar)
             if s in self.scales:
                 out[s] = planar
-        return out
+                out_u8[s] = cur
+        return (out, out_u8) if return_u8 else out
+
+
+def to_tensor(frames: torch.Tensor) -> torch.Tensor:
+    """ToTensor (datasets/utils.py:213-215) of (N,H,W,C) uint8 frames -> (N,C,H,W) float32 = byte / 255."""
+    frames = frames.contiguous()
+    N, H, W, Cc = frames.shape
+    planar = torch.empty(N, Cc, H, W, device=frames.device)
+    _lib.get_lib().call('clslam_u8_to_planar_f32', _pa(frames, torch.uint8), _p(planar), N, H, W, Cc, _stream(frames))
+    return planar
 
 
 BRIGHTNESS, CONTRAST, SATURATION, HUE = 0, 1, 2, 3
