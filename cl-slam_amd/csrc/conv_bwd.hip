@@ -63,6 +63,35 @@ __global__ __launch_bounds__(256) void fold_act_grad_kernel(const float* __restr
         const int b = row / Ho;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         const int ny = pool ? 2 : 1;
+        const int Yf = pool ? 2 * y : y, Xf = pool ? 2 * x : x;
+        // Fast path (all but the two outermost rows / columns): every footprint pixel folds from exactly one
+        // padded position, so the 1 (or 2x2) float4 loads and the 9 head-gradient taps are unconditional and in
+        // flight together.  The general path below walks variable-length lists: one load, one wait at a time.
+        if (Yf >= 2 && Yf + ny - 1 <= H - 3 && Xf >= 2 && Xf + ny - 1 <= W - 3) {
+            float4 v[4];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const int dy = d >> 1, dx = d & 1;
+                if (d < ny * ny && dxp)
+                    v[d] = *reinterpret_cast<const float4*>(dxp + ((size_t)(b * Hp + Yf + dy + e) * Wp + Xf + dx + e) * Cp + c4 * 4);
+                else
+                    v[d] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            if (disp_dz) {      // pool == 0 here: the single padded position (Yf+1, Xf+1) sees the 3x3 neighbourhood of dz
+                float g[9];
+#pragma unroll
+                for (int t = 0; t < 9; ++t) g[t] = disp_dz[((size_t)b * H + Yf - 1 + t / 3) * W + Xf - 1 + t % 3];
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const float4 k = dw[8 - t];      // (2-ky)*3 + (2-kx)
+                    v[0].x = fmaf(g[t], k.x, v[0].x); v[0].y = fmaf(g[t], k.y, v[0].y);
+                    v[0].z = fmaf(g[t], k.z, v[0].z); v[0].w = fmaf(g[t], k.w, v[0].w);
+                }
+            }
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+                if (d < ny * ny) { acc.x += v[d].x; acc.y += v[d].y; acc.z += v[d].z; acc.w += v[d].w; }
+        } else
         for (int dy = 0; dy < ny; ++dy) {
             for (int dx = 0; dx < ny; ++dx) {
                 const int Y = pool ? 2 * y + dy : y, X = pool ? 2 * x + dx : x;

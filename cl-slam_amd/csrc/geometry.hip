@@ -65,15 +65,18 @@ __global__ __launch_bounds__(256) void warp_fwd_kernel(Pyramid pyr, const float*
                                                        const float* __restrict__ P, float* __restrict__ depth_all,
                                                        float* __restrict__ warped_all, int B, int H, int W, float da, float db,
                                                        int dmode) {
-    const size_t per = (size_t)B * H * W;
-    const size_t total = per * pyr.n;
-    for (size_t gidx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; gidx < total; gidx += (size_t)gridDim.x * blockDim.x) {
-        const int sc = (int)(gidx / per);
-        const size_t idx = gidx - (size_t)sc * per;
+    // 32-bit indexing (the host checks 4*B*H*W < 2^31).  The 12 bilinear taps of a frame are loaded
+    // unconditionally from clamped addresses and out-of-image taps get weight 0 (adding 0 leaves the sum
+    // bit-identical): with `if (x1ok) v += pl[..]` every tap was a branch + a load + a wait.
+    const int per = B * H * W;
+    const int total = per * pyr.n;
+    for (int gidx = blockIdx.x * 256 + threadIdx.x; gidx < total; gidx += gridDim.x * 256) {
+        const int sc = gidx / per;
+        const int idx = gidx - sc * per;
         const int h = pyr.h[sc], w = pyr.w[sc];
         float* depth = depth_all + (size_t)sc * per;
         float* warped = warped_all + (size_t)sc * per * 6;
-        const int x = (int)(idx % W), y = (int)((idx / W) % H), b = (int)(idx / ((size_t)W * H));
+        const int x = idx % W, row = idx / W, y = row % H, b = row / H;
         const float disp = upsample_disp(pyr.disp[sc] + (size_t)b * h * w, h, w, H, W, y, x);
         const float dep = disp_to_depth_dev(disp, da, db, dmode);
         depth[idx] = dep;
@@ -81,6 +84,7 @@ __global__ __launch_bounds__(256) void warp_fwd_kernel(Pyramid pyr, const float*
         const float fx = (float)x, fy = (float)y;
         float X[3];
         for (int i = 0; i < 3; ++i) X[i] = dep * (Ki[i * 4 + 0] * fx + Ki[i * 4 + 1] * fy + Ki[i * 4 + 2]);
+#pragma unroll
         for (int fi = 0; fi < 2; ++fi) {
             const float* Pm = P + ((size_t)fi * B + b) * 12;
             float p[3];
@@ -90,13 +94,22 @@ __global__ __launch_bounds__(256) void warp_fwd_kernel(Pyramid pyr, const float*
             const float wx1 = s.ix - (float)s.x0, wy1 = s.iy - (float)s.y0;
             const float wx0 = (float)(s.x0 + 1) - s.ix, wy0 = (float)(s.y0 + 1) - s.iy;
             const bool x1ok = s.x0 + 1 < W, y1ok = s.y0 + 1 < H;
+            const int x1 = x1ok ? s.x0 + 1 : s.x0, y1 = y1ok ? s.y0 + 1 : s.y0;
+            const float w00 = wx0 * wy0, w10 = wx1 * wy0, w01 = wx0 * wy1, w11 = wx1 * wy1;
             const float* src = (fi == 0 ? src_m1 : src_p1) + (size_t)b * 3 * H * W;
+            float nw[3], ne[3], sw[3], se[3];
+#pragma unroll
             for (int c = 0; c < 3; ++c) {
                 const float* pl = src + (size_t)c * H * W;
-                float v = pl[s.y0 * W + s.x0] * (wx0 * wy0);
-                if (x1ok) v += pl[s.y0 * W + s.x0 + 1] * (wx1 * wy0);
-                if (y1ok) v += pl[(s.y0 + 1) * W + s.x0] * (wx0 * wy1);
-                if (x1ok && y1ok) v += pl[(s.y0 + 1) * W + s.x0 + 1] * (wx1 * wy1);
+                nw[c] = pl[s.y0 * W + s.x0]; ne[c] = pl[s.y0 * W + x1];
+                sw[c] = pl[y1 * W + s.x0]; se[c] = pl[y1 * W + x1];
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float v = nw[c] * w00;
+                if (x1ok) v += ne[c] * w10;
+                if (y1ok) v += sw[c] * w01;
+                if (x1ok && y1ok) v += se[c] * w11;
                 warped[(((size_t)fi * B + b) * 3 + c) * H * W + (size_t)y * W + x] = v;
             }
         }
@@ -327,6 +340,7 @@ extern "C" int clslam_warp_fwd_pyramid(const float* const* disp, const float* sr
     for (int k = 0; k < 4; ++k) { pyr.disp[k] = disp[k]; pyr.h[k] = H >> k; pyr.w[k] = W >> k; }
     const size_t total = (size_t)4 * batch * H * W;
     if (!total) return CLSLAM_OK;
+    CLSLAM_REQUIRE(total < ((size_t)1 << 31), "warp_fwd_pyramid: batch too large for 32-bit indexing");
     hipLaunchKernelGGL(warp_fwd_kernel, dim3((unsigned)std::min<size_t>(16384, (total + 255) / 256)), dim3(256), 0,
                        (hipStream_t)stream, pyr, src_m1, src_p1, inv_k, proj, depth, warped, batch, H, W, a, b, mode);
     return check_launch("warp_fwd_pyramid");
