@@ -380,6 +380,18 @@ class Engine:
         aug = {f: self._img(inputs['rgb_aug', f, 0]) for f in (-1, 0, 1)}
         rgb = {f: self._img(inputs['rgb', f, 0]) for f in (-1, 0, 1)}
         B = aug[0].shape[0]
+        # the kernels index with the engine's resolution: refuse anything else up front
+        for name, group in (('rgb_aug', aug), ('rgb', rgb)):
+            for f, t in group.items():
+                if tuple(t.shape) != (B, 3, H, W):
+                    raise ClslamError(f"('{name}', {f}, 0) must be ({B}, 3, {H}, {W}), got {tuple(t.shape)}")
+        for s in range(1, 4):
+            t = inputs['rgb', 0, s]
+            if tuple(t.shape) != (B, 3, H >> s, W >> s):
+                raise ClslamError(f"('rgb', 0, {s}) must be ({B}, 3, {H >> s}, {W >> s}), got {tuple(t.shape)}")
+        for k in (('camera_matrix', 0), ('inv_camera_matrix', 0)):
+            if tuple(inputs[k].shape) != (B, 4, 4):
+                raise ClslamError(f'{k} must be ({B}, 4, 4), got {tuple(inputs[k].shape)}')
         ws = self.workspace(B)
         if train:
             self._train_bufs(ws)

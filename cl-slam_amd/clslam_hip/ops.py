@@ -330,7 +330,10 @@ def avgpool_chunks(hw: int) -> int:
 def global_avgpool(x, out, partial=None):
     """partial: optional (B * avgpool_chunks(HW) * C) scratch -> two-stage reduction over pixel chunks."""
     B, Cc = x.shape[0], x.shape[-1]
-    _lib.get_lib().call('clslam_global_avgpool', _p(x), _p(out), _p(partial), B, x.numel() // (B * Cc), Cc, _stream(out))
+    hw = 1
+    for n in x.shape[1:-1]:
+        hw *= n
+    _lib.get_lib().call('clslam_global_avgpool', _p(x), _p(out), _p(partial), B, hw, Cc, _stream(out))
     return out
 
 

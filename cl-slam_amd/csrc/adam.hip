@@ -51,8 +51,8 @@ using namespace clslam;
 
 extern "C" int clslam_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, double lr,
                                 double beta1, double beta2, double eps, int step, float grad_scale, const float* guard, void* stream) {
-    CLSLAM_REQUIRE(param && grad && exp_avg && exp_avg_sq && step >= 1, "adam_step: bad args");
     if (!n) return CLSLAM_OK;
+    CLSLAM_REQUIRE(param && grad && exp_avg && exp_avg_sq && step >= 1, "adam_step: bad args");
     // scalars are formed in double like torch's python-side arithmetic, then rounded to fp32 once
     const double bc1 = 1.0 - pow(beta1, (double)step);
     const double bc2 = 1.0 - pow(beta2, (double)step);

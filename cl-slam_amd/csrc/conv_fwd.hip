@@ -264,7 +264,9 @@ extern "C" int clslam_conv2d_pick_config(const clslam_conv_desc* d) {
 
 extern "C" int clslam_conv2d(const clslam_conv_desc* d, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    CLSLAM_REQUIRE(d && d->src_a && d->weight && d->out, "conv2d: null pointer");
+    CLSLAM_REQUIRE(d, "conv2d: null descriptor");
+    if (d->batch == 0 || d->out_h * d->out_w == 0) return CLSLAM_OK;   // an empty batch is a no-op (its tensors have no storage)
+    CLSLAM_REQUIRE(d->src_a && d->weight && d->out, "conv2d: null pointer");
     const int Cin = d->ch_a + d->ch_b;
     CLSLAM_REQUIRE(d->ksize == 1 || d->ksize == 3, "conv2d: ksize %d unsupported", d->ksize);
     CLSLAM_REQUIRE(Cin % 16 == 0 && d->ch_a % 16 == 0 && d->ch_out % 16 == 0,
@@ -272,6 +274,10 @@ extern "C" int clslam_conv2d(const clslam_conv_desc* d, void* stream_) {
     CLSLAM_REQUIRE(!d->upsample_a || (d->in_h % 2 == 0 && d->in_w % 2 == 0), "conv2d: upsample needs even dims");
     CLSLAM_REQUIRE(d->pad_mode == CLSLAM_PAD_ZERO || (d->pad < d->in_h && d->pad < d->in_w), "conv2d: reflect pad too large");
     CLSLAM_REQUIRE(d->ch_b == 0 || d->src_b, "conv2d: src_b missing");
+    CLSLAM_REQUIRE(d->stride >= 1 && d->out_h == (d->in_h + 2 * d->pad - d->ksize) / d->stride + 1 &&
+                       d->out_w == (d->in_w + 2 * d->pad - d->ksize) / d->stride + 1,
+                   "conv2d: output size %dx%d does not match input %dx%d, ksize %d, stride %d, pad %d", d->out_h, d->out_w, d->in_h,
+                   d->in_w, d->ksize, d->stride, d->pad);
     ConvK k;
     k.src_a = d->src_a; k.src_b = d->src_b; k.wgt = d->weight; k.scale = d->scale; k.shift = d->shift;
     k.residual = d->residual; k.out = d->out; k.actgrad_src = d->actgrad_src; k.actgrad_kind = d->actgrad_kind;

@@ -180,6 +180,7 @@ extern "C" int clslam_stem_conv(const float* img_a, const float* img_b, const fl
 }
 
 extern "C" int clslam_maxpool3x3s2(const float* in, float* out, int batch, int h, int w, int ch, void* stream) {
+    if (batch == 0) return CLSLAM_OK;
     CLSLAM_REQUIRE(in && out && ch % 4 == 0, "maxpool: bad args");
     const int Ho = (h + 2 - 3) / 2 + 1, Wo = (w + 2 - 3) / 2 + 1;
     const size_t total = (size_t)batch * Ho * Wo * (ch / 4);

@@ -218,6 +218,7 @@ static int grid_for(size_t total) { return (int)std::min<size_t>(4096, (total + 
 
 extern "C" int clslam_dispconv_fwd(const float* x, const float* w, const float* bias, float* disp, int batch, int h,
                                    int wd, int ch, void* stream) {
+    if (batch == 0) return CLSLAM_OK;
     CLSLAM_REQUIRE(x && w && bias && disp && (ch == 16 || ch == 32 || ch == 64 || ch == 128), "dispconv_fwd: ch must be 16/32/64/128");
     const size_t total = (size_t)batch * h * wd;
     if (!total) return CLSLAM_OK;

@@ -235,6 +235,7 @@ extern "C" int clslam_lanczos_plan(int in_size, int out_size, int* bounds, int* 
 extern "C" int clslam_resize_pass_u8(const unsigned char* src, unsigned char* dst, float* planar, const int* bounds,
                                      const int* coeffs, int ksize, int batch, int in_h, int in_w, int ch, int out_size, int axis,
                                      void* stream) {
+    if (batch == 0) return CLSLAM_OK;
     CLSLAM_REQUIRE(src && dst && bounds && coeffs && ksize > 0 && ch >= 1 && ch <= 4 && (axis == 0 || axis == 1) && out_size > 0,
                    "resize_pass_u8: bad args");
     const size_t total = (size_t)batch * (axis == 0 ? out_size : in_h) * (axis == 1 ? out_size : in_w);
@@ -247,6 +248,7 @@ extern "C" int clslam_resize_pass_u8(const unsigned char* src, unsigned char* ds
 }
 
 extern "C" int clslam_u8_to_planar_f32(const unsigned char* src, float* planar, int batch, int h, int w, int ch, void* stream) {
+    if (batch == 0) return CLSLAM_OK;
     CLSLAM_REQUIRE(src && planar && ch >= 1, "u8_to_planar_f32: bad args");
     const size_t total = (size_t)batch * h * w;
     CLSLAM_REQUIRE(total < ((size_t)1 << 31), "u8_to_planar_f32: image too large for 32-bit indexing");
@@ -265,12 +267,14 @@ extern "C" int clslam_color_jitter_u8(const unsigned char* src, unsigned char* d
                                       unsigned long long* lsum, int batch, int h, int w, const int* order, int n_ops,
                                       const double* factors, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    CLSLAM_REQUIRE(src && dst && scratch && lsum && order && factors && n_ops >= 0 && n_ops <= 8, "color_jitter_u8: bad args");
+    CLSLAM_REQUIRE(order && factors && n_ops >= 0 && n_ops <= 8, "color_jitter_u8: bad args");
+    for (int k = 0; k < n_ops; ++k) CLSLAM_REQUIRE(order[k] >= 0 && order[k] <= 3, "color_jitter_u8: unknown op %d", order[k]);
+    CLSLAM_REQUIRE(n_ops == 0 || (factors[3] >= -0.5 && factors[3] <= 0.5), "color_jitter_u8: hue_factor outside [-0.5, 0.5]");
+    if (batch == 0) return CLSLAM_OK;
+    CLSLAM_REQUIRE(src && dst && scratch && lsum, "color_jitter_u8: null pointer");
     const size_t total = (size_t)batch * h * w;
     CLSLAM_REQUIRE(total < ((size_t)1 << 30), "color_jitter_u8: image too large for 32-bit indexing");
     if (!total) return CLSLAM_OK;
-    for (int k = 0; k < n_ops; ++k) CLSLAM_REQUIRE(order[k] >= 0 && order[k] <= 3, "color_jitter_u8: unknown op %d", order[k]);
-    CLSLAM_REQUIRE(n_ops == 0 || (factors[3] >= -0.5 && factors[3] <= 0.5), "color_jitter_u8: hue_factor outside [-0.5, 0.5]");
     const unsigned blocks = (unsigned)std::min<size_t>(4096, (total + 255) / 256);
     if (n_ops == 0) {
         hipMemcpyAsync(dst, src, total * 3, hipMemcpyDeviceToDevice, stream);

@@ -194,8 +194,8 @@ extern "C" int clslam_dwconv(const float* x, const float* weight, const float* s
 extern "C" int clslam_avgpool_chunks(int hw) { return std::max(1, std::min(64, hw / 64)); }
 
 extern "C" int clslam_global_avgpool(const float* x, float* out, float* partial, int batch, int hw, int ch, void* stream) {
-    CLSLAM_REQUIRE(x && out && ch % 4 == 0 && hw > 0, "global_avgpool: bad args");
     if (!batch) return CLSLAM_OK;
+    CLSLAM_REQUIRE(x && out && ch % 4 == 0 && hw > 0, "global_avgpool: bad args");
     const int nch = partial ? clslam_avgpool_chunks(hw) : 1;
     hipLaunchKernelGGL(global_avgpool_kernel, dim3(cdiv(ch, 64), batch, nch), dim3(256), 0, (hipStream_t)stream, x, out, partial,
                        hw, ch, cdiv(hw, nch));

@@ -1,0 +1,65 @@
+"""Edge cases of the C ABI and the Python boundary: empty batches are no-ops, invalid arguments come back as
+error codes + clslam_last_error() (ClslamError on the Python side, never a crash), shapes the kernels cannot
+tile are refused up front, and the predictor validates like the reference's constructor (dpp.py:87-120)."""
+import pytest
+import torch
+
+from clslam_hip import ops
+from clslam_hip._lib import ClslamError
+from emu_util import BACKENDS, use_backend
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_empty_batches_are_no_ops(backend):
+    dev = use_backend(backend)
+    z = lambda *s: torch.zeros(*s, device=dev)   # noqa: E731
+    out = torch.full((0, 8, 8, 16), 1.0, device=dev)
+    ops.conv2d(z(0, 8, 8, 16), z(16, 9, 16), out, ksize=3)
+    ops.maxpool3x3s2(z(0, 8, 8, 64), z(0, 4, 4, 64))
+    ops.dispconv_fwd(z(0, 8, 8, 16), z(9, 16), z(1), z(0, 8, 8))
+    ops.adam_step(z(0), z(0), z(0), z(0), 1e-4, 1)
+    ops.global_avgpool(z(0, 4, 4, 16), z(0, 16))
+    from clslam_hip.ingest import ImagePyramid, color_jitter
+    assert ImagePyramid(32, 64)(torch.zeros(0, 40, 70, 3, dtype=torch.uint8, device=dev))[3].shape == (0, 3, 4, 8)
+    assert color_jitter(torch.zeros(0, 8, 8, 3, dtype=torch.uint8, device=dev), [0, 3], [1.1, 1, 1, 0.1]).shape == (0, 8, 8, 3)
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_invalid_arguments_raise_with_message(backend):
+    dev = use_backend(backend)
+    z = lambda *s: torch.zeros(*s, device=dev)   # noqa: E731
+    with pytest.raises(ClslamError, match='multiples of 16'):
+        ops.conv2d(z(1, 8, 8, 12), z(16, 9, 12), z(1, 8, 8, 16), ksize=3)            # channel count the MFMA tiles cannot take
+    with pytest.raises(ClslamError, match='ksize'):
+        ops.conv2d(z(1, 8, 8, 16), z(16, 25, 16), z(1, 8, 8, 16), ksize=5, pad=2)
+    with pytest.raises(ClslamError, match='output size'):
+        ops.conv2d(z(1, 4, 4, 16), z(16, 9, 16), z(1, 9, 9, 16), ksize=3, upsample_a=True, pad=1)   # 8x8 in, 9x9 out
+    with pytest.raises(ClslamError):
+        ops.conv2d(z(1, 8, 8, 16).double(), z(16, 9, 16), z(1, 8, 8, 16), ksize=3)   # dtype checked before the call
+    with pytest.raises(ClslamError):
+        ops.conv2d(z(1, 8, 8, 32)[..., ::2], z(16, 9, 16), z(1, 8, 8, 16), ksize=3)  # non-contiguous
+    with pytest.raises(ClslamError, match='hue'):
+        from clslam_hip.ingest import color_jitter
+        color_jitter(torch.zeros(1, 4, 4, 3, dtype=torch.uint8, device=dev), [3], [1, 1, 1, 0.7])
+    # the error state does not stick: a good call afterwards works
+    out = torch.full((1, 8, 8, 16), float('nan'), device=dev)
+    ops.conv2d(z(1, 8, 8, 16), z(16, 9, 16), out, ksize=3)
+    assert float(out.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_predictor_validation_matches_reference_constructor(backend):
+    """dpp.py:87-120 and the engine's own shape contract."""
+    use_backend(backend)
+    from predictor_util import make_predictor
+    with pytest.raises(ValueError):
+        make_predictor(60, 128, 1)                       # not a multiple of 32: five stride-2 stages
+    with pytest.raises((ValueError, NotImplementedError)):
+        make_predictor(64, 128, 1, multiple_gpus=True)   # nn.DataParallel mode is not provided (one process per GPU)
+    p = make_predictor(64, 128, 2)
+    from clslam_hip import synth
+    bad = synth.make_batch(3, 64, 128, seed=0)           # batch of 3 under a configured batch_size of 2 (dpp.py:1031-1032)
+    with pytest.raises(RuntimeError, match='must match'):
+        p.adapt(None, bad, steps=1)
+    with pytest.raises(ClslamError):
+        p.predict({k: (v[..., :96] if v.dim() == 4 else v) for k, v in synth.make_batch(1, 64, 128, seed=0).items()})   # wrong width
