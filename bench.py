@@ -180,7 +180,7 @@ def main():
                  16: '8, 16, 32, 16, 16, 4, false, 4, 1', 17: '4, 16, 16, 16, 16, 4, false, 4, 1', 18: '4, 16, 16, 16, 16, 4, true, 4, 1',
                  19: '8, 16, 16, 16, 16, 4, true, 4, 1', 20: '8, 16, 16, 16, 16, 4, false, 8, 1', 21: '4, 16, 16, 16, 16, 4, false, 8, 1',
                  22: '4, 16, 16, 16, 16, 4, true, 8, 1', 23: '4, 16, 16, 16, 16, 4, false, 8, 2', 24: '4, 16, 16, 32, 16, 4, true, 8, 1',
-                 25: '4, 16, 16, 32, 16, 4, false, 8, 1'}
+                 25: '4, 16, 16, 32, 16, 4, false, 8, 1', 26: '4, 8, 32, 16, 16, 2, false, 8, 1'}
         names = {0: 'conv_igemm_kernel<128, 64, 32, 32, 2>', 1: 'conv_igemm_kernel<64, 64, 32, 32, 2>',
                  2: 'conv_igemm_kernel<32, 32, 32, 16, 2>', 3: 'conv_igemm_kernel<64, 32, 32, 16, 2>',
                  4: 'conv_igemm_kernel<128, 16, 16, 16, 4>', 5: 'conv_igemm_kernel<64, 32, 16, 16, 2>',

@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(PatchK p) {
     constexpr int P_SLOTS = PP * F4, W_SLOTS = 9 * BN * F4;
     constexpr int P_IT = (P_SLOTS + 255) / 256, W_IT = (W_SLOTS + 255) / 256;
     constexpr int NACC = MF == 32 ? 16 : 4;
-    static_assert(WM % MF == 0 && WN % MF == 0 && BK % KSTEP == 0 && TW % 16 == 0, "tile shape");
+    static_assert(WM % MF == 0 && WN % MF == 0 && BK % KSTEP == 0 && TW % 8 == 0, "tile shape");
 
     __shared__ __attribute__((aligned(16))) float Ps[PP * LD];
     __shared__ __attribute__((aligned(16))) float Wsm[9 * BN * LD];
@@ -375,7 +375,8 @@ static int launch_patch(PatchK k, hipStream_t stream) {
 // Called by clslam_conv2d for configs >= 10.
 int conv3x3_patch_dispatch(const clslam_conv_desc* d, int cfg, hipStream_t stream) {
     const int st = d->stride;
-    if (d->ksize != 3 || (st != 1 && st != 2) || (st == 2) != (cfg == 23) || ((cfg == 24 || cfg == 25) && (d->ch_a + d->ch_b) % 32 != 0)) {
+    if (d->ksize != 3 || (st != 1 && st != 2) || (st == 2) != (cfg == 23) || ((cfg == 24 || cfg == 25) && (d->ch_a + d->ch_b) % 32 != 0) ||
+        (cfg == 26 && d->ch_out % 32 != 0)) {
         set_error("conv2d: patch configs need a 3x3 conv with stride 1 (configs 10-22) or 2 (config 23)");
         return CLSLAM_ERR_INVALID;
     }
@@ -412,6 +413,8 @@ int conv3x3_patch_dispatch(const clslam_conv_desc* d, int cfg, hipStream_t strea
         case 23: return launch_patch<4, 16, 16, 16, 16, 4, false, 8, 2, true>(k, stream);  // stride-2 convs (encoder stage entries)
         case 24: return launch_patch<4, 16, 16, 32, 16, 4, true, 8>(k, stream);   // = 22 with BK = 32 (half the chunks: latency-bound layers)
         case 25: return launch_patch<4, 16, 16, 32, 16, 4, false, 8>(k, stream);  // = 21 with BK = 32
+        case 26: return launch_patch<4, 8, 32, 16, 16, 2, false, 8>(k, stream);   // 4x8 px x 32 ch: images whose width is a multiple
+                                                                                   // of 8 but not 16 (12x40: 4x16 tiles waste 1/6)
         default: set_error("conv2d: unknown patch config %d", cfg); return CLSLAM_ERR_INVALID;
     }
 }

@@ -58,6 +58,9 @@ CASES = [
     (2, 12, 40, 16, 16, 32, 3, 1, 1, True, 2, False, 18),
     (2, 2, 4, 32, 0, 16, 3, 1, 1, False, 2, False, 18),
     (2, 12, 40, 32, 0, 32, 3, 1, 0, False, 1, False, 19),
+    (2, 12, 40, 48, 0, 64, 3, 1, 0, False, 1, True, 26),     # 4x8 px x 32 ch tiles, width 40
+    (1, 10, 24, 32, 32, 32, 3, 1, 1, True, 2, False, 26),    # ragged rows, upsample + concat, reflect
+    (1, 14, 44, 16, 0, 32, 3, 1, 0, False, 0, False, 26),    # dgrad-like padded domain (12x40 + 2)
     (1, 5, 22, 16, 0, 16, 3, 1, 0, False, 0, False, 19),
     (1, 10, 36, 32, 0, 32, 3, 1, 1, False, 2, False, 20),
     (2, 6, 20, 32, 0, 48, 3, 1, 0, False, 1, False, 21),
