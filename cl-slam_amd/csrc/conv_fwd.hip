@@ -249,10 +249,11 @@ extern "C" int clslam_conv2d_pick_config(const clslam_conv_desc* d) {
     // B=5 @192x640): 128 px x 16 ch tiles reach 80-104 TFLOP/s on the >= 48x160 layers, 64 px x 16 ch
     // tiles 65-95 TFLOP/s on the smaller ones, 64-px row-major runs 46-70 TFLOP/s on the 6x20 layers
     // (a 4x16 rectangle wastes half its lanes there); all beat every conv_igemm tiling (26-67).
-    if (d->ksize == 3 && d->stride == 1 && d->out_h == d->in_h + 2 * d->pad - 2 && d->out_w == d->in_w + 2 * d->pad - 2)
+    if (d->ksize == 3 && d->stride == 1 && d->out_h == d->in_h + 2 * d->pad - 2 && d->out_w == d->in_w + 2 * d->pad - 2) {
         if (d->out_w <= 24) return 22;                         // narrow images: run tiles
         // (config 26, 4x8 px x 32 ch tiles without overhang on 12x40, measured 67 vs 69 TFLOP/s for config 21: not picked)
         return M >= 30000 ? 20 : 21;                           // 20/21/22 = 12/17/18 with conflict-free LDS rows
+    }
     if (d->ksize == 3 && d->stride == 2 && d->out_h == (d->in_h + 2 * d->pad - 3) / 2 + 1 && d->out_w == (d->in_w + 2 * d->pad - 3) / 2 + 1)
         return 23;
     if (d->ch_out % 32 != 0) return bk32 ? 6 : 4;

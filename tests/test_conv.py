@@ -43,6 +43,11 @@ CASES = [
     (3, 12, 20, 64, 0, 64, 3, 1, 0, False, 1, True, 0),
     (1, 4, 6, 16, 0, 32, 3, 1, 0, False, 0, False, 5),
     (2, 6, 20, 64, 0, 128, 3, 1, 0, False, 1, False, -1),
+    # config -1 (the library picks) for every conv family of the networks: 1x1 stride 2 / stride 1, 3x3 stride 2, wide 3x3
+    (2, 12, 20, 64, 0, 128, 1, 2, 0, False, 0, False, -1),
+    (2, 6, 10, 64, 0, 32, 1, 1, 0, False, 1, False, -1),
+    (2, 12, 40, 32, 0, 64, 3, 2, 0, False, 1, False, -1),
+    (1, 16, 48, 32, 16, 16, 3, 1, 1, True, 2, False, -1),
     # LDS-patch kernel (configs 10-13): ragged tiles, reflect/zero, upsample + concat, residual
     (2, 12, 20, 32, 0, 64, 3, 1, 0, False, 1, True, 10),
     (1, 10, 36, 64, 64, 64, 3, 1, 1, True, 2, False, 10),
