@@ -8,11 +8,13 @@ One "step" = one `DepthPosePrediction.adapt(online, training, steps=1)`: forward
 view synthesis + loss, hand-written backward, fused Adam -- on a synthetic minibatch of 1 online
 triplet + R replayed triplets that is already resident in HBM (BASELINE.json metric).
 N = 1 runs BASELINE config 3 (R = 4, B = 5, the configuration the 30 frames/s target is quoted on);
-`--replay R` selects another per-GPU replay count (R = 0 is BASELINE config 2).
-N > 1 shards a minibatch of B = 1 + R*N triplets data-parallel (rank 0: online + R, others R each;
-R = 4, N = 8 is BASELINE config 4, K = 32) with ONE sum-all-reduce of the flat gradient arena per step
-over RCCL/xGMI.  `value` counts frames of (1+R) triplets: value = steps/s * B/(1+R), so N = 1 is plain
-frames/s and per-GPU work stays fixed as N grows ("weak").
+`--replay R` selects another replay count (R = 0 is BASELINE config 2).
+N > 1 shards a minibatch data-parallel with ONE sum-all-reduce of the flat gradient arena per step over
+RCCL/xGMI.  By default every rank gets the N = 1 shard size, 1+R triplets (rank 0: the online triplet + R
+replayed ones, the others 1+R replayed ones; B = N*(1+R), K = B-1), so per-GPU work is exactly fixed as N
+grows ("weak").  `--total-replay K` instead shards a minibatch of 1+K triplets as evenly as possible
+(`--gpus 8 --total-replay 32` is BASELINE config 4: shards 5,4,4,4,4,4,4,4).  `value` counts frames of
+(1+R) triplets: value = steps/s * B/(1+R), so N = 1 is plain frames/s.
 
 Rank 0 prints ONE JSON line (contract in the task description) with `roofline` (dominant kernel:
 the fp32-MFMA implicit-GEMM conv, algorithmic FLOPs / HIP-event launch time vs the 157.3 TFLOP/s
@@ -84,7 +86,9 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=30)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--replay', type=int, default=4, help='replay triplets per GPU (global K = replay * gpus)')
+    ap.add_argument('--replay', type=int, default=4, help='replay triplets of the N=1 minibatch; every rank gets 1+replay triplets')
+    ap.add_argument('--total-replay', type=int, default=None, help='shard a minibatch of 1+K triplets over the ranks instead '
+                    '(8 GPUs, K=32: BASELINE config 4)')
     ap.add_argument('--height', type=int, default=192)
     ap.add_argument('--width', type=int, default=640)
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -111,9 +115,9 @@ def main():
         else:
             dist.init_process_group(args.backend)
 
-    K = args.replay * N
-    B = 1 + K
     FRAME_TRIPLETS = 1 + args.replay   # a "frame" = the N=1 minibatch: 1 online + R replay triplets
+    B = N * FRAME_TRIPLETS if args.total_replay is None else 1 + args.total_replay
+    K = B - 1
     # contiguous shards, rank 0 holds the online sample (+ the remainder)
     base, rem = divmod(B, N)
     counts = [base + (1 if r < rem else 0) for r in range(N)]
