@@ -133,6 +133,14 @@ class Engine:
         for st in (self.side_stream, self.wg_stream, self.capture_stream):
             if st is not None:
                 self._conv_workspace(st.cuda_stream)
+        # Asynchronous tail (data-parallel mode): gradient reduction + all-reduce + Adam of step N run on their own
+        # stream; the caller's stream does not wait for them, so the frozen encoders of step N+1 overlap the
+        # xGMI all-reduce.  Whatever reads trainable state waits on the event (wait_training()).
+        self.async_tail = False
+        self.tail_stream = torch.cuda.Stream(device=device) if device.type == 'cuda' else None
+        self._tail_event = None       # optimizer step in flight on tail_stream
+        self._tail_open = False       # backward() left its reduction on tail_stream; adam() closes it
+        self._capturing = False
         self.depth_first = os.environ.get('CLSLAM_DEPTH_FIRST', '1') != '0'
         self.use_side_stream = os.environ.get('CLSLAM_SIDE_STREAM', '1') != '0'
 
@@ -160,9 +168,24 @@ class Engine:
                                   'call sync_modules() first')
             self.pack()
 
+    def _use_tail(self) -> bool:
+        return (self.async_tail and self.tail_stream is not None and self.device.type == 'cuda' and not self._capturing
+                and ops.PROFILE is None)
+
+    def wait_training(self, stream=None) -> None:
+        """Make `stream` (default: the current one) wait for the optimizer step in flight on the tail stream."""
+        if self._tail_event is not None:
+            (stream or torch.cuda.current_stream(self.device)).wait_event(self._tail_event)
+
+    def training_stream(self):
+        """Context manager: the stream the gradient all-reduce of the step in flight belongs on."""
+        import contextlib
+        return torch.cuda.stream(self.tail_stream) if self._tail_open else contextlib.nullcontext()
+
     @torch.no_grad()
     def pack(self) -> None:
         dev = self.device
+        self.wait_training()
         for which in ('depth_encoder', 'pose_encoder'):
             sd = {k: v.detach().to(dev, torch.float32) for k, v in torch.nn.Module.state_dict(self.models[which]).items()}
             e = SimpleNamespace()
@@ -203,6 +226,7 @@ class Engine:
         """Write the engine's adapted weights back into the module parameters (reference layout)."""
         if not self._modules_stale or self.models is None:
             return
+        self.wait_training()
         for name, off, shape in self.layout.entries:
             model, key = name.split('/', 1)
             p = torch.nn.Module.state_dict(self.models[model], keep_vars=True)[key]
@@ -211,6 +235,7 @@ class Engine:
         self._packed_version = self._module_version()
 
     def wview(self, name: str) -> torch.Tensor:
+        self.wait_training()
         for n, off, shape in self.layout.entries:
             if n == name:
                 return self.w[off:off + math.prod(shape)]
@@ -438,6 +463,7 @@ class Engine:
                     # pose pairs in temporal order (dpp.py:949-955): (-1, 0) and (0, +1), batched as 2B
                     pf = self._encoder(self.enc['pose_encoder'], ws.penc, 2 * B,
                                        [(aug[-1], aug[0], 0, B), (aug[0], aug[1], B, B)])
+                    self.wait_training(side)      # the (frozen) encoder above does not need the optimizer step in flight
                     self._pose_decoder(ws, pf[4])
                     return pf
             # the host enqueues ~50 launches per branch (~0.7 ms): the depth branch is the longer
@@ -445,13 +471,16 @@ class Engine:
             if self.depth_first:
                 dfeats = self._encoder(self.enc['depth_encoder'], ws.denc, B, [(aug[0], None, 0, B)])
                 pfeats = pose_branch()
+                self.wait_training(main)
                 self._depth_decoder(ws, dfeats)
             else:
                 pfeats = pose_branch()
                 dfeats = self._encoder(self.enc['depth_encoder'], ws.denc, B, [(aug[0], None, 0, B)])
+                self.wait_training(main)
                 self._depth_decoder(ws, dfeats)
             main.wait_stream(side)
         else:
+            self.wait_training()
             dfeats = self._encoder(self.enc['depth_encoder'], ws.denc, B, [(aug[0], None, 0, B)])
             self._depth_decoder(ws, dfeats)
             pfeats = self._encoder(self.enc['pose_encoder'], ws.penc, 2 * B, [(aug[-1], aug[0], 0, B), (aug[0], aug[1], B, B)])
@@ -593,7 +622,15 @@ class Engine:
         # one batched, deterministic reduction of every weight / bias gradient partial into the arena
         if t.table is None:
             t.table = ops.make_reduce_table(t.items, self.device)
-        ops.reduce_multi(t.table, len(t.items), self.g)
+        if self._use_tail():
+            # the partial buffers are complete on the current stream; the reduction, the all-reduce (caller, under
+            # training_stream()) and Adam follow on the tail stream and nobody waits for them here
+            self.tail_stream.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(self.tail_stream):
+                ops.reduce_multi(t.table, len(t.items), self.g)
+            self._tail_open = True
+        else:
+            ops.reduce_multi(t.table, len(t.items), self.g)
 
     def _transpose_decoder_weights(self, t) -> None:
         """Flipped/transposed upconv weights for the dgrad convs.  They depend only on the weights, so all
@@ -763,6 +800,8 @@ class Engine:
                 return out, losses
             fresh = self.fresh_outputs
             self.fresh_outputs = False          # the graph writes into static planes; copies are handed out
+            self._capturing = True              # no asynchronous tail inside a captured step
+            self.wait_training()
             try:
                 cur = torch.cuda.current_stream(self.device)
                 warm = torch.cuda.Stream(device=self.device)
@@ -777,6 +816,8 @@ class Engine:
                 st.graph = g
             finally:
                 self.fresh_outputs = fresh
+                self._capturing = False
+        self.wait_training()
         st.graph.replay()
         outputs = {k: v.clone() for k, v in st.outputs.items()}
         return outputs, st.losses.clone()
@@ -785,7 +826,18 @@ class Engine:
     def adam(self, lr: float, betas=(0.9, 0.999), eps: float = 1e-8, guard: Optional[torch.Tensor] = None) -> None:
         """guard: the step's loss (1 element); a NaN there makes the kernel skip the update."""
         self.adam_step_count += 1
-        ops.adam_step(self.w, self.g, self.m, self.v, lr, self.adam_step_count, betas[0], betas[1], eps, guard=guard)
+        if self._tail_open:
+            if guard is not None:
+                guard.record_stream(self.tail_stream)      # a fresh per-call tensor allocated on the caller's stream
+            with torch.cuda.stream(self.tail_stream):
+                ops.adam_step(self.w, self.g, self.m, self.v, lr, self.adam_step_count, betas[0], betas[1], eps, guard=guard)
+                self._tail_event = torch.cuda.Event()
+                self._tail_event.record(self.tail_stream)
+            self._tail_open = False
+        else:
+            self.wait_training()
+            ops.adam_step(self.w, self.g, self.m, self.v, lr, self.adam_step_count, betas[0], betas[1], eps, guard=guard)
+            self._tail_event = None
         self._modules_stale = True
 
     # ------------------------------------------------------------------------------------------
@@ -815,6 +867,7 @@ class Engine:
         """predict_pose (dpp.py:628-664): pose_encoder(cat(img0,img1)) -> pose_decoder; returns (n,12)."""
         self.pack_if_needed()
         self._conv_workspace()
+        self.wait_training()
         a, b = self._img(image_0.to(self.device)), self._img(image_1.to(self.device))
         n = a.shape[0]
         key = ('pose', n)

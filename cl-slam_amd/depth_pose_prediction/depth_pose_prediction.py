@@ -17,6 +17,7 @@ libclslam_hip.so raises.  Offline pre-training / evaluation / plotting (dpp.py:2
 """
 import math
 import shutil
+import os
 import warnings
 from pathlib import Path
 from typing import Any, Dict, Optional, Tuple, Union
@@ -54,6 +55,7 @@ class EngineAdam(optim.Adam):
     def state_dict(self):
         sd = super().state_dict()
         eng = self._engine
+        eng.wait_training()
         state = {}
         if eng.adam_step_count > 0:
             for idx, name in enumerate(self._names):
@@ -72,6 +74,7 @@ class EngineAdam(optim.Adam):
     @torch.no_grad()
     def load_state_dict(self, state_dict) -> None:
         eng = self._engine
+        eng.wait_training()
         groups = state_dict['param_groups']
         if len(groups) != 1 or len(groups[0]['params']) != len(self._names):
             raise ValueError('loaded state dict contains a parameter group that does not match the size of '
@@ -232,6 +235,8 @@ class DepthPosePrediction:
         if not dist.is_initialized():
             raise RuntimeError('torch.distributed is not initialised')
         self._dp = dict(group=process_group, global_batch=int(global_batch_size), offset=int(shard_offset), dist=dist)
+        # overlap the gradient all-reduce + Adam with the next step's (frozen) encoders
+        self.engine.async_tail = os.environ.get('CLSLAM_ASYNC_TAIL', '1') != '0'
 
     def set_tie_break_noise(self, noise: Optional[Dict[int, Tensor]]) -> None:
         """Parity testing only: inject the per-scale tie-break tensors (B,2,H,W) that the reference
@@ -489,7 +494,8 @@ class DepthPosePrediction:
 
     def _reduce_gradients(self) -> None:
         if self._dp is not None:
-            self._dp['dist'].all_reduce(self.engine.g, group=self._dp['group'])
+            with self.engine.training_stream():     # the tail stream when the engine left the reduction there
+                self._dp['dist'].all_reduce(self.engine.g, group=self._dp['group'])
 
 
 def _select_device() -> torch.device:

@@ -132,6 +132,7 @@ def test_conv2d_split_k(backend, case, monkeypatch):
                     ups=ups, act=act)
     t = lambda v: None if v is None else v.to(dev)   # noqa: E731
     ws = torch.zeros(4 << 20, dtype=torch.uint8, device=dev)
+    monkeypatch.setattr(ops, '_CONV_WORKSPACES', {})     # engines of earlier tests register per-stream scratch: not here
     monkeypatch.setenv('CLSLAM_SPLITK', '3' if Ca + Cb >= 256 else '2')
     outs = []
     for workspace in (ws, ws, None):
