@@ -143,6 +143,8 @@ class Engine:
         self._capturing = False
         self.depth_first = os.environ.get('CLSLAM_DEPTH_FIRST', '1') != '0'
         self.use_side_stream = os.environ.get('CLSLAM_SIDE_STREAM', '1') != '0'
+        # steps 2..S of adapt(steps=S) keep the frozen encoders' features (see forward)
+        self.reuse_frozen_features = os.environ.get('CLSLAM_REUSE_FROZEN', '1') != '0'
 
     # ------------------------------------------------------------------------------------------
     # parameters
@@ -220,6 +222,9 @@ class Engine:
             self.w[off:off + flat.numel()].copy_(flat)
         self._packed_version = self._module_version()
         self._modules_stale = False
+        for ws in self._ws.values():           # features of the previous encoder weights are void
+            if hasattr(ws, 'frozen_valid'):
+                ws.frozen_valid = False
 
     @torch.no_grad()
     def sync_modules(self) -> None:
@@ -398,8 +403,15 @@ class Engine:
     # ------------------------------------------------------------------------------------------
     def forward(self, inputs: Dict[Any, torch.Tensor], *, train: bool, sample_w: torch.Tensor,
                 smooth_w: Optional[torch.Tensor], noise: Optional[Dict[int, torch.Tensor]] = None,
-                draw_noise: bool = True, keep_noise: bool = False) -> Tuple[Dict[Any, torch.Tensor], torch.Tensor]:
-        """One _process_batch (dpp.py:906-923).  `inputs` tensors must already live on the device."""
+                draw_noise: bool = True, keep_noise: bool = False,
+                reuse_frozen: bool = False) -> Tuple[Dict[Any, torch.Tensor], torch.Tensor]:
+        """One _process_batch (dpp.py:906-923).  `inputs` tensors must already live on the device.
+
+        reuse_frozen: the caller guarantees that `inputs` are the tensors of the previous forward of this
+        batch size (steps 2..S of one adapt(steps=S) call, dpp.py:309-313).  Both encoders are frozen and in
+        eval mode there (dpp.py:308), so their features and the identity-reprojection maps are bit-for-bit
+        what the previous step computed: they are kept instead of recomputed (54 % of a step's forward
+        flops).  Ignored when no valid features are held."""
         H, W = self.H, self.W
         self._conv_workspace()
         aug = {f: self._img(inputs['rgb_aug', f, 0]) for f in (-1, 0, 1)}
@@ -418,6 +430,8 @@ class Engine:
             if tuple(inputs[k].shape) != (B, 4, 4):
                 raise ClslamError(f'{k} must be ({B}, 4, 4), got {tuple(inputs[k].shape)}')
         ws = self.workspace(B)
+        reuse = bool(reuse_frozen and self.reuse_frozen_features and getattr(ws, 'frozen_valid', False))
+        ws.frozen_valid = False
         if train:
             self._train_bufs(ws)
         if self.fresh_outputs:
@@ -429,9 +443,10 @@ class Engine:
             ws.depth, ws.warped, ws.losses = E(4, B, H, W), E(4, 2, B, 3, H, W), E(18)
         def identity_and_noise() -> bool:
             """Identity reprojection maps (dpp.py:1047-1052) and the tie-break noise depend on the inputs only."""
-            ws.idsrc[0].copy_(rgb[-1])
-            ws.idsrc[1].copy_(rgb[1])
-            ops.photo_map(ws.idsrc, rgb[0], ws.idmap, None, 2 * B, B, H, W)
+            if not reuse:
+                ws.idsrc[0].copy_(rgb[-1])
+                ws.idsrc[1].copy_(rgb[1])
+                ops.photo_map(ws.idsrc, rgb[0], ws.idmap, None, 2 * B, B, H, W)
             if noise is not None:
                 for s in range(4):
                     ws.noise[s].copy_(noise[s])
@@ -461,31 +476,35 @@ class Engine:
             def pose_branch():
                 with torch.cuda.stream(side):
                     # pose pairs in temporal order (dpp.py:949-955): (-1, 0) and (0, +1), batched as 2B
-                    pf = self._encoder(self.enc['pose_encoder'], ws.penc, 2 * B,
-                                       [(aug[-1], aug[0], 0, B), (aug[0], aug[1], B, B)])
+                    pf4 = ws.pf4 if reuse else self._encoder(self.enc['pose_encoder'], ws.penc, 2 * B,
+                                                             [(aug[-1], aug[0], 0, B), (aug[0], aug[1], B, B)])[4]
                     self.wait_training(side)      # the (frozen) encoder above does not need the optimizer step in flight
-                    self._pose_decoder(ws, pf[4])
-                    return pf
+                    self._pose_decoder(ws, pf4)
+                    return pf4
+
+            def depth_encoder():
+                return ws.dfeats if reuse else self._encoder(self.enc['depth_encoder'], ws.denc, B, [(aug[0], None, 0, B)])
             # the host enqueues ~50 launches per branch (~0.7 ms): the depth branch is the longer
             # dependency chain (encoder + decoder), so its kernels go out first
             if self.depth_first:
-                dfeats = self._encoder(self.enc['depth_encoder'], ws.denc, B, [(aug[0], None, 0, B)])
-                pfeats = pose_branch()
+                dfeats = depth_encoder()
+                pf4 = pose_branch()
                 self.wait_training(main)
                 self._depth_decoder(ws, dfeats)
             else:
-                pfeats = pose_branch()
-                dfeats = self._encoder(self.enc['depth_encoder'], ws.denc, B, [(aug[0], None, 0, B)])
+                pf4 = pose_branch()
+                dfeats = depth_encoder()
                 self.wait_training(main)
                 self._depth_decoder(ws, dfeats)
             main.wait_stream(side)
         else:
             self.wait_training()
-            dfeats = self._encoder(self.enc['depth_encoder'], ws.denc, B, [(aug[0], None, 0, B)])
+            dfeats = ws.dfeats if reuse else self._encoder(self.enc['depth_encoder'], ws.denc, B, [(aug[0], None, 0, B)])
             self._depth_decoder(ws, dfeats)
-            pfeats = self._encoder(self.enc['pose_encoder'], ws.penc, 2 * B, [(aug[-1], aug[0], 0, B), (aug[0], aug[1], B, B)])
-            self._pose_decoder(ws, pfeats[4])
-        ws.dfeats, ws.pf4 = dfeats, pfeats[4]
+            pf4 = ws.pf4 if reuse else self._encoder(self.enc['pose_encoder'], ws.penc, 2 * B,
+                                                     [(aug[-1], aug[0], 0, B), (aug[0], aug[1], B, B)])[4]
+            self._pose_decoder(ws, pf4)
+        ws.dfeats, ws.pf4 = dfeats, pf4
         # view synthesis + loss ------------------------------------------------------------------
         K = self._mat(inputs['camera_matrix', 0])
         Kinv = self._mat(inputs['inv_camera_matrix', 0])
@@ -515,6 +534,7 @@ class Engine:
                           n_smooth, self.smooth_scale, self.vel_scale)
         ws.ctx = SimpleNamespace(rgb=rgb, K=K, Kinv=Kinv, d0=d0, d1=d1, sample_w=sample_w, n_smooth=n_smooth,
                                  aux=aux if n_smooth else None, B=B)
+        ws.frozen_valid = True      # encoder features + identity maps of THESE inputs and encoder weights are held
         return self._outputs(ws, B), ws.losses
 
     def _img(self, t: torch.Tensor) -> torch.Tensor:
@@ -769,15 +789,17 @@ class Engine:
         return self.graphs_enabled() and (mode == '1' or B <= 2)
 
     def train_step_graphed(self, inputs: Dict[Any, torch.Tensor], *, sample_w: torch.Tensor, smooth_w: Optional[torch.Tensor],
-                           noise: Optional[Dict[int, torch.Tensor]], copy_inputs: bool = True):
+                           noise: Optional[Dict[int, torch.Tensor]], copy_inputs: bool = True,
+                           reuse_frozen: bool = False):
         """forward(train=True) + backward() through a captured hipGraph (captured on first use per
-        batch size / noise mode).  Returns (outputs, losses) as fresh tensors."""
+        batch size / noise mode; a second, encoder-free graph serves the reuse_frozen steps).  Returns
+        (outputs, losses) as fresh tensors."""
         B = inputs['rgb_aug', 0, 0].shape[0]
         key = (B, noise is not None, 0 if smooth_w is None else int(smooth_w.numel()))
         st = self._graphs.get(key)
         if st is None:
-            st = SimpleNamespace(graph=None, inputs={}, sample_w=sample_w.clone(),
-                                 smooth_w=None if smooth_w is None else smooth_w.clone(), outputs=None, losses=None)
+            st = SimpleNamespace(graphs={}, inputs={}, sample_w=sample_w.clone(),
+                                 smooth_w=None if smooth_w is None else smooth_w.clone())
             for k in self.GRAPH_KEYS:
                 v = inputs[k]
                 st.inputs[k] = (v.to(torch.float64) if k[0] == 'relative_distance' else self._img(v)).clone()
@@ -792,10 +814,15 @@ class Engine:
         if noise is not None:
             for s in range(4):
                 ws.noise[s].copy_(noise[s], non_blocking=True)
-        if st.graph is None:
+        reuse = bool(reuse_frozen and not copy_inputs and self.reuse_frozen_features and getattr(ws, 'frozen_valid', False))
+        entry = st.graphs.get(reuse)
+        if entry is None:
+            entry = SimpleNamespace(graph=None, outputs=None, losses=None)
+
             def run():
                 out, losses = self.forward(st.inputs, train=True, sample_w=st.sample_w, smooth_w=st.smooth_w,
-                                           noise=None, draw_noise=noise is None, keep_noise=noise is not None)
+                                           noise=None, draw_noise=noise is None, keep_noise=noise is not None,
+                                           reuse_frozen=reuse)
                 self.backward(B)
                 return out, losses
             fresh = self.fresh_outputs
@@ -812,15 +839,17 @@ class Engine:
                 torch.cuda.synchronize(self.device)
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, stream=self.capture_stream):
-                    st.outputs, st.losses = run()
-                st.graph = g
+                    entry.outputs, entry.losses = run()
+                entry.graph = g
+                st.graphs[reuse] = entry
             finally:
                 self.fresh_outputs = fresh
                 self._capturing = False
         self.wait_training()
-        st.graph.replay()
-        outputs = {k: v.clone() for k, v in st.outputs.items()}
-        return outputs, st.losses.clone()
+        entry.graph.replay()
+        ws.frozen_valid = True
+        outputs = {k: v.clone() for k, v in entry.outputs.items()}
+        return outputs, entry.losses.clone()
 
     # ------------------------------------------------------------------------------------------
     def adam(self, lr: float, betas=(0.9, 0.999), eps: float = 1e-8, guard: Optional[torch.Tensor] = None) -> None:

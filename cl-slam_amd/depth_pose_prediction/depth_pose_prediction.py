@@ -271,14 +271,17 @@ class DepthPosePrediction:
             self._set_adapt(freeze_encoder=True)
             self.engine.pack_if_needed()
             for it in range(steps):
+                # steps 2..S see the same minibatch through the same frozen, eval-mode encoders (dpp.py:308-313):
+                # their features and the identity-reprojection maps are kept, only the decoders re-run
                 if self.engine.graph_preferred(training_data['rgb_aug', 0, 0].shape[0]):
                     # forward + backward replayed as one hipGraph (same kernels, same streams)
                     outputs_eval, losses = self._process_batch(training_data, loss_weights, train=True, graphed=True,
-                                                               copy_inputs=(it == 0))
+                                                               copy_inputs=(it == 0), reuse_frozen=(it > 0))
                     self.optimizer.zero_grad()
                     self._reduce_gradients()
                 else:
-                    outputs_eval, losses = self._process_batch(training_data, loss_weights, train=True)
+                    outputs_eval, losses = self._process_batch(training_data, loss_weights, train=True,
+                                                               reuse_frozen=(it > 0))
                     self.optimizer.zero_grad()
                     self._backward(training_data)
                 # dpp.py:1115-1118 aborts on a NaN loss before backward/step.  Checking there costs a full host
@@ -448,17 +451,19 @@ class DepthPosePrediction:
         return w, w
 
     def _process_batch(self, inputs: Dict[Any, Tensor], loss_sample_weights: Optional[Tensor] = None,
-                       use_online: bool = False, train: bool = False, graphed: bool = False, copy_inputs: bool = True):
+                       use_online: bool = False, train: bool = False, graphed: bool = False, copy_inputs: bool = True,
+                       reuse_frozen: bool = False):
         for key, val in inputs.items():  # mutates the caller's dict, like dpp.py:916-917
             inputs[key] = val.to(self.device)
         B = inputs['rgb_aug', 0, 0].shape[0]
         sample_w, smooth_w = self._sample_weights(B, loss_sample_weights)
         if graphed:
             outputs, losses = self.engine.train_step_graphed(inputs, sample_w=sample_w, smooth_w=smooth_w,
-                                                             noise=self._injected_noise, copy_inputs=copy_inputs)
+                                                             noise=self._injected_noise, copy_inputs=copy_inputs,
+                                                             reuse_frozen=reuse_frozen)
         else:
             outputs, losses = self.engine.forward(inputs, train=train, sample_w=sample_w, smooth_w=smooth_w,
-                                                  noise=self._injected_noise)
+                                                  noise=self._injected_noise, reuse_frozen=reuse_frozen)
         if self._dp is not None:
             self._dp['dist'].all_reduce(losses, group=self._dp['group'])
         loss_dict = self.engine.losses_dict(losses)
