@@ -486,7 +486,12 @@ class Engine:
                 return ws.dfeats if reuse else self._encoder(self.enc['depth_encoder'], ws.denc, B, [(aug[0], None, 0, B)])
             # the host enqueues ~50 launches per branch (~0.7 ms): the depth branch is the longer
             # dependency chain (encoder + decoder), so its kernels go out first
-            if self.depth_first:
+            if reuse:                   # no encoders to hide the host's launches behind: the long chain goes out first
+                dfeats = ws.dfeats
+                self.wait_training(main)
+                self._depth_decoder(ws, dfeats)
+                pf4 = pose_branch()
+            elif self.depth_first:
                 dfeats = depth_encoder()
                 pf4 = pose_branch()
                 self.wait_training(main)
@@ -790,7 +795,7 @@ class Engine:
 
     def train_step_graphed(self, inputs: Dict[Any, torch.Tensor], *, sample_w: torch.Tensor, smooth_w: Optional[torch.Tensor],
                            noise: Optional[Dict[int, torch.Tensor]], copy_inputs: bool = True,
-                           reuse_frozen: bool = False):
+                           reuse_frozen: bool = False, want_outputs: bool = True):
         """forward(train=True) + backward() through a captured hipGraph (captured on first use per
         batch size / noise mode; a second, encoder-free graph serves the reuse_frozen steps).  Returns
         (outputs, losses) as fresh tensors."""
@@ -848,7 +853,9 @@ class Engine:
         self.wait_training()
         entry.graph.replay()
         ws.frozen_valid = True
-        outputs = {k: v.clone() for k, v in entry.outputs.items()}
+        # the graph writes static planes: hand out copies (skipped for the intermediate steps of adapt(steps=S),
+        # whose outputs the caller drops -- dpp.py:309-319 returns the last step's only)
+        outputs = {k: v.clone() for k, v in entry.outputs.items()} if want_outputs else {}
         return outputs, entry.losses.clone()
 
     # ------------------------------------------------------------------------------------------

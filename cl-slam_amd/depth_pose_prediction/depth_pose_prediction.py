@@ -218,6 +218,7 @@ class DepthPosePrediction:
         self.train_loader, self.val_loader = None, None
 
         self._dp = None
+        self._default_weights: Dict[Any, Any] = {}
         self._injected_noise = None
         self._loss_host = None   # pinned 1-float staging buffer + event for the per-step NaN check
         self._loss_event = None
@@ -276,7 +277,8 @@ class DepthPosePrediction:
                 if self.engine.graph_preferred(training_data['rgb_aug', 0, 0].shape[0]):
                     # forward + backward replayed as one hipGraph (same kernels, same streams)
                     outputs_eval, losses = self._process_batch(training_data, loss_weights, train=True, graphed=True,
-                                                               copy_inputs=(it == 0), reuse_frozen=(it > 0))
+                                                               copy_inputs=(it == 0), reuse_frozen=(it > 0),
+                                                               want_outputs=(it == steps - 1))
                     self.optimizer.zero_grad()
                     self._reduce_gradients()
                 else:
@@ -434,6 +436,15 @@ class DepthPosePrediction:
     def _sample_weights(self, B: int, loss_sample_weights: Optional[Tensor]):
         """dpp.py:1031-1032 and the broadcasting of a (batch_size,) weight vector against the actual
         batch (equal sizes, or an actual batch of 1 which sees the SUM of the weights)."""
+        if loss_sample_weights is None:      # the default vectors are constants: built once per batch size
+            key = (B, None if self._dp is None else (self._dp['global_batch'], self._dp['offset']))
+            hit = self._default_weights.get(key)
+            if hit is None:
+                hit = self._default_weights[key] = self._build_sample_weights(B, None)
+            return hit
+        return self._build_sample_weights(B, loss_sample_weights)
+
+    def _build_sample_weights(self, B: int, loss_sample_weights: Optional[Tensor]):
         if self._dp is not None:
             gb = self._dp['global_batch']
             w = torch.full((gb,), 1.0 / gb, device=self.device) if loss_sample_weights is None else loss_sample_weights
@@ -452,15 +463,16 @@ class DepthPosePrediction:
 
     def _process_batch(self, inputs: Dict[Any, Tensor], loss_sample_weights: Optional[Tensor] = None,
                        use_online: bool = False, train: bool = False, graphed: bool = False, copy_inputs: bool = True,
-                       reuse_frozen: bool = False):
-        for key, val in inputs.items():  # mutates the caller's dict, like dpp.py:916-917
-            inputs[key] = val.to(self.device)
+                       reuse_frozen: bool = False, want_outputs: bool = True):
+        if not reuse_frozen:             # steps 2..S of one adapt() call see the dict this loop already moved
+            for key, val in inputs.items():  # mutates the caller's dict, like dpp.py:916-917
+                inputs[key] = val.to(self.device)
         B = inputs['rgb_aug', 0, 0].shape[0]
         sample_w, smooth_w = self._sample_weights(B, loss_sample_weights)
         if graphed:
             outputs, losses = self.engine.train_step_graphed(inputs, sample_w=sample_w, smooth_w=smooth_w,
                                                              noise=self._injected_noise, copy_inputs=copy_inputs,
-                                                             reuse_frozen=reuse_frozen)
+                                                             reuse_frozen=reuse_frozen, want_outputs=want_outputs)
         else:
             outputs, losses = self.engine.forward(inputs, train=train, sample_w=sample_w, smooth_w=smooth_w,
                                                   noise=self._injected_noise, reuse_frozen=reuse_frozen)
