@@ -94,6 +94,7 @@ def main():
     ap.add_argument('--height', type=int, default=192)
     ap.add_argument('--width', type=int, default=640)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-also', action='store_true', help='skip the extra adapt(steps=5) timing (profiling runs)')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo lets two '
                     'ranks share one GPU for a functional check of the sharded path)')
     ap.add_argument('--dump-convs', action='store_true', help='per-launch conv timings to stderr')
@@ -209,7 +210,7 @@ def main():
                 'all_conv_launches': {'achieved': round(all_fl / all_t / 1e12, 2), 'time_ms_per_step': round(all_t * 1e3, 3),
                                       'gflop_per_step': round(all_fl / 1e9, 2)}}
     also = None
-    if N == 1 and S == 1:
+    if N == 1 and S == 1 and not args.no_also:
         # the reference's shipped configuration (config_adapt.yaml:53, adaptation_epochs: 5): five optimizer steps
         # per incoming frame; steps 2..5 keep the frozen encoders' features (engine.forward reuse_frozen)
         for _ in range(2):

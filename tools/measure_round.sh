@@ -13,7 +13,7 @@ python bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 prof() {   # name, env..., then bench args after --
     local name=$1; shift
     rm -rf /tmp/prof_$name
-    (cd /tmp && env "$@" rocprofv3 --kernel-trace --stats -d /tmp/prof_$name -o run -- python $OLDPWD/bench.py --steps 10 --warmup 3 --no-cpu-baseline > /tmp/prof_$name.log 2>&1)
+    (cd /tmp && env "$@" rocprofv3 --kernel-trace --stats -d /tmp/prof_$name -o run -- python $OLDPWD/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-also > /tmp/prof_$name.log 2>&1)
     local db=$(ls /tmp/prof_$name/*/*.db /tmp/prof_$name/*.db 2>/dev/null | head -1)
     python tools/rocprof_summary.py $db $OUT/${TAG}_kernel_stats_$name.csv
 }
@@ -21,13 +21,14 @@ prof 3streams CLSLAM_SIDE_STREAM=1
 prof serial CLSLAM_SIDE_STREAM=0
 for ctr in FETCH_SIZE WRITE_SIZE; do
     rm -rf /tmp/pmc_$ctr
-    (cd /tmp && CLSLAM_SIDE_STREAM=0 rocprofv3 --pmc $ctr -d /tmp/pmc_$ctr -o run -- python $OLDPWD/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /tmp/pmc_$ctr.log 2>&1)
+    (cd /tmp && CLSLAM_SIDE_STREAM=0 rocprofv3 --pmc $ctr -d /tmp/pmc_$ctr -o run -- python $OLDPWD/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-also > /tmp/pmc_$ctr.log 2>&1)
     db=$(ls /tmp/pmc_$ctr/*/*.db /tmp/pmc_$ctr/*.db 2>/dev/null | head -1)
     python tools/pmc_summary.py $db conv > $OUT/${TAG}_pmc_$ctr.txt 2>&1
 done
+brief() { python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print({k: d.get(k) for k in ('value', 'unit', 'ms_per_step', 'also')}, d['config']['workload'][:70])"; }
 {
-  for r in 0 2 32; do echo "== 192x640 replay $r"; python bench.py --replay $r --steps 20 --warmup 5 --no-cpu-baseline | cut -c1-260; done
-  echo "== 384x1280 replay 8"; python bench.py --height 384 --width 1280 --replay 8 --steps 10 --warmup 3 --no-cpu-baseline | cut -c1-260
+  for r in 0 2 32; do echo "== 192x640 replay $r"; python bench.py --replay $r --steps 20 --warmup 5 --no-cpu-baseline | brief; done
+  echo "== 384x1280 replay 8"; python bench.py --height 384 --width 1280 --replay 8 --steps 10 --warmup 3 --no-cpu-baseline | brief
 } > $OUT/${TAG}_other_configs.txt 2>&1
 BENCH_WGRAD=1 python tools/bench_conv.py > $OUT/${TAG}_conv_microbench.txt 2>&1
 python tools/bench_small.py > $OUT/${TAG}_small_kernels.txt 2>&1
