@@ -239,6 +239,32 @@ class DepthPosePrediction:
         # overlap the gradient all-reduce + Adam with the next step's (frozen) encoders
         self.engine.async_tail = os.environ.get('CLSLAM_ASYNC_TAIL', '1') != '0'
 
+    def gather_outputs(self, outputs: Dict[Any, Tensor]) -> Dict[Any, Tensor]:
+        """Data-parallel mode: every rank's `outputs` shard concatenated in rank (= sample) order on every
+        rank -- the full-batch dict a single process would have returned.  slam.py only reads sample 0,
+        which rank 0 already holds, so nothing on the per-frame path calls this; it is the explicit
+        collective for callers that want all samples.  Shards may be uneven."""
+        if self._dp is None:
+            return outputs
+        dist, group = self._dp['dist'], self._dp['group']
+        world = dist.get_world_size(group)
+        n_local = next(iter(outputs.values())).shape[0]
+        counts = [torch.zeros(1, dtype=torch.int64, device=self.device) for _ in range(world)]
+        dist.all_gather(counts, torch.tensor([n_local], dtype=torch.int64, device=self.device), group=group)
+        counts = [int(c) for c in counts]
+        if sum(counts) != self._dp['global_batch']:
+            raise RuntimeError(f'shards {counts} do not add up to the global batch {self._dp["global_batch"]}')
+        cap = max(counts)
+        full: Dict[Any, Tensor] = {}
+        for key, val in outputs.items():
+            val = val.contiguous()
+            if n_local < cap:        # all_gather wants equal shapes: pad the short shards
+                val = torch.cat([val, val.new_zeros((cap - n_local,) + tuple(val.shape[1:]))])
+            parts = [torch.empty_like(val) for _ in range(world)]
+            dist.all_gather(parts, val, group=group)
+            full[key] = torch.cat([part[:c] for part, c in zip(parts, counts)])
+        return full
+
     def set_tie_break_noise(self, noise: Optional[Dict[int, Tensor]]) -> None:
         """Parity testing only: inject the per-scale tie-break tensors (B,2,H,W) that the reference
         draws with torch.randn(...) * 1e-5 (dpp.py:1055-1056).  None -> draw on the device."""

@@ -32,7 +32,9 @@ def _worker(rank, world, port, counts, out_dir):
     p.set_tie_break_noise({s: v[off:off + counts[rank]] for s, v in noise.items()})
     batch = {k: v[off:off + counts[rank]].clone() for k, v in full.items()}
     out, losses = p.adapt(None, batch, steps=1)
-    torch.save({'g': p.engine.g.clone(), 'w': p.engine.w.clone(), 'loss': {k: v.clone() for k, v in losses.items()},
+    everything = p.gather_outputs(out)               # uneven shards (2 + 1)
+    torch.save({'full_depth': everything['depth', 0].clone(), 'full_T': everything['cam_T_cam', 0, -1].clone(),
+                'g': p.engine.g.clone(), 'w': p.engine.w.clone(), 'loss': {k: v.clone() for k, v in losses.items()},
                 'T': out['cam_T_cam', 0, 1].clone()}, Path(out_dir) / f'rank{rank}.pt')
     dist.destroy_process_group()
 
@@ -62,3 +64,9 @@ def test_two_ranks_equal_single_rank(tmp_path):
     for k, v in losses.items():
         assert abs(float(r0['loss'][k]) - float(v)) <= 2e-6 * max(abs(float(v)), 1e-3), k
     assert torch.allclose(r0['T'], out['cam_T_cam', 0, 1][:2], atol=1e-7)
+    # the explicit all-gather helper: the single-process full-batch dict, identical on both ranks
+    for r in (r0, r1):
+        assert r['full_depth'].shape == out['depth', 0].shape
+        assert torch.equal(r['full_depth'], r0['full_depth'])
+        assert torch.allclose(r['full_depth'], out['depth', 0], rtol=1e-6, atol=0)
+        assert torch.allclose(r['full_T'], out['cam_T_cam', 0, -1], atol=1e-7)
