@@ -265,6 +265,26 @@ class DepthPosePrediction:
             full[key] = torch.cat([part[:c] for part, c in zip(parts, counts)])
         return full
 
+    def replicas_in_sync(self) -> bool:
+        """Data-parallel mode: True when every rank holds bit-identical trainable weights and Adam moments
+        (they should: same all-reduced gradient, same update).  Two tiny all-reduces of a checksum triple;
+        meant to be called every N frames, not per step."""
+        if self._dp is None:
+            return True
+        self.engine.wait_training()
+        e = self.engine
+        # order-dependent checksums of the raw bit patterns: a single flipped bit anywhere changes them
+        def digest(t):
+            bits = t.view(torch.int32).to(torch.int64)
+            idx = torch.arange(1, bits.numel() + 1, device=bits.device, dtype=torch.int64)
+            return torch.stack([bits.sum(), (bits * (idx % 8191 + 1)).sum()])
+        mine = torch.cat([digest(e.w), digest(e.m), digest(e.v)])
+        lo, hi = mine.clone(), mine.clone()
+        dist, group = self._dp['dist'], self._dp['group']
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+        return bool(torch.equal(lo, hi))
+
     def set_tie_break_noise(self, noise: Optional[Dict[int, Tensor]]) -> None:
         """Parity testing only: inject the per-scale tie-break tensors (B,2,H,W) that the reference
         draws with torch.randn(...) * 1e-5 (dpp.py:1055-1056).  None -> draw on the device."""

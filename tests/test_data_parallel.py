@@ -33,7 +33,13 @@ def _worker(rank, world, port, counts, out_dir):
     batch = {k: v[off:off + counts[rank]].clone() for k, v in full.items()}
     out, losses = p.adapt(None, batch, steps=1)
     everything = p.gather_outputs(out)               # uneven shards (2 + 1)
-    torch.save({'full_depth': everything['depth', 0].clone(), 'full_T': everything['cam_T_cam', 0, -1].clone(),
+    in_sync = p.replicas_in_sync()
+    if rank == 1:                                    # a single flipped mantissa bit on one rank must be noticed
+        p.engine.w.view(torch.int32)[12345] ^= 1
+    diverged_seen = not p.replicas_in_sync()
+    if rank == 1:
+        p.engine.w.view(torch.int32)[12345] ^= 1
+    torch.save({'in_sync': in_sync, 'diverged_seen': diverged_seen, 'full_depth': everything['depth', 0].clone(), 'full_T': everything['cam_T_cam', 0, -1].clone(),
                 'g': p.engine.g.clone(), 'w': p.engine.w.clone(), 'loss': {k: v.clone() for k, v in losses.items()},
                 'T': out['cam_T_cam', 0, 1].clone()}, Path(out_dir) / f'rank{rank}.pt')
     dist.destroy_process_group()
@@ -66,6 +72,7 @@ def test_two_ranks_equal_single_rank(tmp_path):
     assert torch.allclose(r0['T'], out['cam_T_cam', 0, 1][:2], atol=1e-7)
     # the explicit all-gather helper: the single-process full-batch dict, identical on both ranks
     for r in (r0, r1):
+        assert r['in_sync'] and r['diverged_seen']
         assert r['full_depth'].shape == out['depth', 0].shape
         assert torch.equal(r['full_depth'], r0['full_depth'])
         assert torch.allclose(r['full_depth'], out['depth', 0], rtol=1e-6, atol=0)
