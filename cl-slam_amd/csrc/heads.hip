@@ -10,42 +10,62 @@ namespace clslam {
 
 // ------------------------------------------------------------------------------------------------
 // disp[b,y,x] = sigmoid(bias + sum_{tap,c} x[b, refl(y+ky-1), refl(x+kx-1), c] * w[tap][c])
-// C/4 lanes cooperate on one pixel (one float4 of channels each, 9 taps), then a butterfly over those
-// lanes; a wave covers 256/C pixels, loads are 16-byte and contiguous across the lanes of a pixel.
+// A workgroup owns a TH x TW pixel tile: its (TH+2) x (TW+2) x C input patch is staged ONCE in LDS with
+// contiguous 16-byte loads (reflection resolved while staging), so every input element crosses L2 about 1.4
+// times instead of 9.  C/4 lanes then cooperate on one pixel (one float4 of channels each, 9 taps from LDS --
+// the lanes of a wave read 1 KiB of consecutive LDS, conflict-free), a butterfly over those lanes finishes it.
+template <int C, int TW, int TH>
 __global__ __launch_bounds__(256) void dispconv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                            const float* __restrict__ bias, float* __restrict__ disp,
-                                                           int B, int H, int W, int C) {
-    const int C4 = C / 4;                       // power of two in {4, 8, 16, 32}
-    const int ppb = 256 / C4;                   // pixels per block
+                                                           int B, int H, int W, int tiles_x, int tiles_y) {
+    constexpr int C4 = C / 4;                   // lanes per pixel: 4, 8, 16, 32
+    constexpr int PPI = 256 / C4;               // pixels per pass of the workgroup
+    constexpr int PW = TW + 2, PH = TH + 2;
+    static_assert((TW * TH) % PPI == 0 && PPI <= TW * TH, "tile must be a whole number of passes");
+    __shared__ float4 tile[PH * PW * C4];
+    const int tx = blockIdx.x % tiles_x, ty = (blockIdx.x / tiles_x) % tiles_y, b = blockIdx.x / (tiles_x * tiles_y);
+    const int x0 = tx * TW, y0 = ty * TH;
     const int cq = threadIdx.x % C4, pl = threadIdx.x / C4;
-    const size_t total = (size_t)B * H * W;
-    const float bv = bias[0];
     float4 wv[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) wv[t] = *reinterpret_cast<const float4*>(w + t * C + cq * 4);
-    // every lane of the wave runs the same number of iterations (the shuffles need all lanes)
-    const size_t iters = (total + (size_t)gridDim.x * ppb - 1) / ((size_t)gridDim.x * ppb);
-    for (size_t itn = 0; itn < iters; ++itn) {
-        const size_t idx = (itn * gridDim.x + blockIdx.x) * ppb + pl;
-        const bool ok = idx < total;
-        const size_t id = ok ? idx : 0;
-        const int xx = (int)(id % W), yy = (int)((id / W) % H), b = (int)(id / ((size_t)W * H));
+    const float bv = bias[0];
+    for (int e = threadIdx.x; e < PH * PW * C4; e += 256) {
+        const int c4 = e % C4, px = (e / C4) % PW, py = e / (C4 * PW);
+        // rows / columns past the image only occur in partial tiles and feed no stored pixel: clamp them
+        const int iy = reflect_idx(min(y0 + py - 1, H), H), ix = reflect_idx(min(x0 + px - 1, W), W);
+        tile[e] = *reinterpret_cast<const float4*>(x + (((size_t)b * H + iy) * W + ix) * C + c4 * 4);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < TW * TH / PPI; ++it) {
+        const int p = it * PPI + pl;
+        const int lx = p % TW, ly = p / TW;
         float acc = 0.f;
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
-            const int iy = reflect_idx(yy + ky - 1, H);
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
-                const int ix = reflect_idx(xx + kx - 1, W);
-                const float4 v = *reinterpret_cast<const float4*>(x + (((size_t)b * H + iy) * W + ix) * C + cq * 4);
+                const float4 v = tile[((ly + ky) * PW + lx + kx) * C4 + cq];
                 const float4 k = wv[ky * 3 + kx];
                 acc = fmaf(v.x, k.x, acc); acc = fmaf(v.y, k.y, acc);
                 acc = fmaf(v.z, k.z, acc); acc = fmaf(v.w, k.w, acc);
             }
         }
+#pragma unroll
         for (int m = C4 >> 1; m >= 1; m >>= 1) acc += wave_shfl_xor(acc, m);
-        if (ok && cq == 0) disp[idx] = 1.f / (1.f + expf(-(acc + bv)));
+        const int xx = x0 + lx, yy = y0 + ly;
+        if (cq == 0 && xx < W && yy < H) disp[((size_t)b * H + yy) * W + xx] = 1.f / (1.f + expf(-(acc + bv)));
     }
+}
+
+template <int C, int TW, int TH>
+static int launch_dispconv_fwd(const float* x, const float* w, const float* bias, float* disp, int batch, int h, int wd,
+                               hipStream_t stream) {
+    const int tiles_x = cdiv(wd, TW), tiles_y = cdiv(h, TH);
+    hipLaunchKernelGGL((dispconv_fwd_kernel<C, TW, TH>), dim3(tiles_x * tiles_y * batch), dim3(256), 0, stream, x, w, bias,
+                       disp, batch, h, wd, tiles_x, tiles_y);
+    return check_launch("dispconv_fwd");
 }
 
 // dxp[b,Py,Px,c] (+)= sum_{ky,kx} dz[b,Py-2+ky,Px-2+kx] * w[(2-ky)*3+(2-kx)][c]   (padded domain)
@@ -220,11 +240,15 @@ extern "C" int clslam_dispconv_fwd(const float* x, const float* w, const float* 
                                    int wd, int ch, void* stream) {
     if (batch == 0) return CLSLAM_OK;
     CLSLAM_REQUIRE(x && w && bias && disp && (ch == 16 || ch == 32 || ch == 64 || ch == 128), "dispconv_fwd: ch must be 16/32/64/128");
-    const size_t total = (size_t)batch * h * wd;
-    if (!total) return CLSLAM_OK;
-    hipLaunchKernelGGL(dispconv_fwd_kernel, dim3(grid_for(total * (ch / 4))), dim3(256), 0, (hipStream_t)stream, x, w, bias, disp,
-                       batch, h, wd, ch);
-    return check_launch("dispconv_fwd");
+    CLSLAM_REQUIRE(h >= 2 && wd >= 2, "dispconv_fwd: reflection padding needs at least 2x2 pixels");
+    hipStream_t st = (hipStream_t)stream;
+    // tile shapes: 22-31 KiB of LDS each, a whole number of 256-lane passes, halo overhead 1.3-1.9x
+    switch (ch) {
+        case 16: return launch_dispconv_fwd<16, 32, 8>(x, w, bias, disp, batch, h, wd, st);
+        case 32: return launch_dispconv_fwd<32, 32, 4>(x, w, bias, disp, batch, h, wd, st);
+        case 64: return launch_dispconv_fwd<64, 16, 4>(x, w, bias, disp, batch, h, wd, st);
+        default: return launch_dispconv_fwd<128, 8, 4>(x, w, bias, disp, batch, h, wd, st);
+    }
 }
 
 extern "C" int clslam_dispconv_bwd_data(const float* dz, const float* w, float* dxp, int batch, int h, int wd, int ch,

@@ -32,7 +32,8 @@ def test_stem_and_maxpool(backend, n_img, B, H, W):
 
 
 @pytest.mark.parametrize('backend', BACKENDS)
-@pytest.mark.parametrize('B,H,W,C', [(2, 8, 12, 16), (1, 6, 10, 128), (3, 4, 8, 32), (1, 7, 9, 64)])
+@pytest.mark.parametrize('B,H,W,C', [(2, 8, 12, 16), (1, 6, 10, 128), (3, 4, 8, 32), (1, 7, 9, 64),
+                                     (2, 20, 70, 16), (1, 9, 40, 32), (2, 10, 35, 64), (1, 11, 19, 128)])  # several tiles, ragged edges
 def test_dispconv_fwd_bwd(backend, B, H, W, C):
     dev = use_backend(backend)
     g = torch.Generator().manual_seed(7)
