@@ -330,7 +330,9 @@ class Engine:
         t.dz_sq = torch.empty_like(ws.sq)
         t.plan, t.items, t.table, t.disp_part = {}, [], None, {}
         t.side = SimpleNamespace(wt=E(256 * 9 * 256))
-        t.bias_part = {k: E(1024 * v.shape[-1]) for k, v in ws.x.items()}   # fused bias-grad partials per layer
+        # fused bias-grad partials per layer: one row per fold workgroup (pooled folds run at the resolution of x)
+        t.bias_part = {k: E(ops.fold_blocks(v.shape[0], v.shape[1], v.shape[2], v.shape[3], False) * v.shape[-1])
+                       for k, v in ws.x.items()}
         ws.train = t
         return t
 

@@ -457,6 +457,7 @@ extern "C" int clslam_weight_transpose(const float* w, float* wt, int ch_out, in
 
 extern "C" int clslam_fold_blocks(int batch, int h, int w, int ch, int pool) {
     const size_t total = (size_t)batch * (pool ? h / 2 : h) * (pool ? w / 2 : w) * (ch / 4);
+    // more workgroups do not help (measured 1024..8192: 33 -> 39 us at 192x640x16): the pass is HBM read+write bound
     return (int)std::max<size_t>(1, std::min<size_t>(1024, (total + 255) / 256));
 }
 
