@@ -31,6 +31,10 @@ class ConvDesc(C.Structure):
                 ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t)]
 
 
+class CopyItem(C.Structure):
+    _fields_ = [('src', C.c_void_p), ('dst', C.c_void_p), ('bytes', C.c_size_t)]
+
+
 class LossDesc(C.Structure):
     _fields_ = [('partial', fptr * 4), ('disp', fptr * 4), ('rgb0', fptr * 4), ('means', fptr * 4),
                 ('pose', fptr), ('dist0', fptr), ('dist1', fptr), ('sample_w', fptr), ('smooth_w', fptr),
@@ -106,6 +110,7 @@ _SIGNATURES = {
     'clslam_adam_step': [fptr, fptr, fptr, fptr, C.c_size_t, C.c_double, C.c_double, C.c_double, C.c_double, i32, C.c_float,
                          fptr, C.c_void_p],
     'clslam_disp_grad': [fptr, fptr, fptr, i32, fptr, i32, i32, i32, i32, i32, C.c_void_p],
+    'clslam_copy_multi': [C.c_void_p, i32, C.c_void_p],
 }
 _RESTYPES = {'clslam_last_error': C.c_char_p}
 

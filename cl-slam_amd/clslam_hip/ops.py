@@ -157,6 +157,22 @@ def reduce_multi(table, nitems, stream_ref, blocks_per_item=384):
     _lib.get_lib().call('clslam_reduce_multi', table.data_ptr(), nitems, blocks_per_item, _stream(stream_ref))
 
 
+def copy_multi(pairs, stream_ref=None):
+    """pairs: [(src, dst), ...] device tensors of equal dtype / byte size, both contiguous -> one launch for all
+    copies (instead of one torch copy kernel each)."""
+    pairs = [(s, d) for s, d in pairs if d.numel()]
+    if not pairs:
+        return
+    items = (_lib.CopyItem * len(pairs))()
+    for it, (src, dst) in zip(items, pairs):
+        if (src.dtype != dst.dtype or src.numel() != dst.numel() or src.device != dst.device
+                or not src.is_contiguous() or not dst.is_contiguous()):
+            raise _lib.ClslamError(f'copy_multi: {tuple(src.shape)} {src.dtype} {src.device} -> '
+                                   f'{tuple(dst.shape)} {dst.dtype} {dst.device} is not a plain copy')
+        it.src, it.dst, it.bytes = src.data_ptr(), dst.data_ptr(), src.numel() * src.element_size()
+    _lib.get_lib().call('clslam_copy_multi', C.cast(items, C.c_void_p), len(pairs), _stream(stream_ref if stream_ref is not None else pairs[0][1]))
+
+
 def colsum_blocks(rows: int) -> int:
     return _lib.get_lib().cdll.clslam_colsum_blocks(rows)
 

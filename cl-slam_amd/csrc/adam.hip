@@ -45,9 +45,61 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Up to kCopyBatch independent device-to-device copies in ONE launch (item table passed by value in the
+// kernel arguments: no table upload).  blockIdx.y = item; 16-byte path when pointers and size allow it.
+constexpr int kCopyBatch = 24;
+struct CopyBatch {
+    const void* src[kCopyBatch];
+    void* dst[kCopyBatch];
+    unsigned long long bytes[kCopyBatch];
+};
+
+__global__ __launch_bounds__(256) void copy_multi_kernel(CopyBatch b) {
+    const int item = blockIdx.y;
+    const unsigned long long bytes = b.bytes[item];
+    const char* src = static_cast<const char*>(b.src[item]);
+    char* dst = static_cast<char*>(b.dst[item]);
+    const size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x, stride = (size_t)gridDim.x * 256;
+    if ((((unsigned long long)(uintptr_t)src | (unsigned long long)(uintptr_t)dst | bytes) & 15ull) == 0) {
+        const float4* s4 = reinterpret_cast<const float4*>(src);
+        float4* d4 = reinterpret_cast<float4*>(dst);
+        for (size_t i = tid; i < bytes / 16; i += stride) d4[i] = s4[i];
+    } else if ((((unsigned long long)(uintptr_t)src | (unsigned long long)(uintptr_t)dst | bytes) & 3ull) == 0) {
+        const unsigned* s1 = reinterpret_cast<const unsigned*>(src);
+        unsigned* d1 = reinterpret_cast<unsigned*>(dst);
+        for (size_t i = tid; i < bytes / 4; i += stride) d1[i] = s1[i];
+    } else {
+        for (size_t i = tid; i < bytes; i += stride) dst[i] = src[i];
+    }
+}
+
 }  // namespace clslam
 
 using namespace clslam;
+
+extern "C" int clslam_copy_multi(const clslam_copy_item* items, int nitems, void* stream) {
+    CLSLAM_REQUIRE(nitems >= 0 && (items || nitems == 0), "copy_multi: bad args");
+    for (int base = 0; base < nitems; base += kCopyBatch) {
+        CopyBatch b;
+        int n = 0;
+        unsigned long long largest = 0;
+        for (int i = base; i < nitems && n < kCopyBatch; ++i) {
+            if (items[i].bytes == 0) continue;
+            CLSLAM_REQUIRE(items[i].src && items[i].dst, "copy_multi: null pointer with a non-zero size");
+            b.src[n] = items[i].src; b.dst[n] = items[i].dst; b.bytes[n] = items[i].bytes;
+            largest = std::max<unsigned long long>(largest, items[i].bytes);
+            ++n;
+        }
+        if (!n) continue;
+        // 4 KiB per workgroup pass; small tables (a few 100 KiB per item) stay at a handful of workgroups per item
+        const unsigned bx = (unsigned)std::min<unsigned long long>(128, std::max<unsigned long long>(1, (largest + 16383) / 16384));
+        hipLaunchKernelGGL(copy_multi_kernel, dim3(bx, n), dim3(256), 0, (hipStream_t)stream, b);
+        const int rc = check_launch("copy_multi");
+        if (rc != CLSLAM_OK) return rc;
+    }
+    return CLSLAM_OK;
+}
 
 extern "C" int clslam_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, double lr,
                                 double beta1, double beta2, double eps, int step, float grad_scale, const float* guard, void* stream) {

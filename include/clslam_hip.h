@@ -259,6 +259,18 @@ int clslam_adam_step(float* param, const float* grad, float* exp_avg, float* exp
                      double beta1, double beta2, double eps, int step, float grad_scale, const float* guard, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * nitems independent device-to-device copies in one launch (items is a HOST array; sizes in bytes,
+ * any alignment).  No reference counterpart: it replaces the per-tensor copies a hipGraph-replayed
+ * step needs around the replay -- the sample dict of dpp.py:916-917 into the graph's static inputs and
+ * the static output planes into the fresh tensors adapt()/predict() hand back (dpp.py:319).          */
+typedef struct clslam_copy_item {
+    const void* src;
+    void* dst;
+    size_t bytes;
+} clslam_copy_item;
+int clslam_copy_multi(const clslam_copy_item* items, int nitems, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Image-pyramid ingest: the reference's datasets resize every pyramid level from the
  * previous one with torchvision.transforms.Resize(LANCZOS) on PIL images (datasets/utils.py:62-66,154-163)
  * = Pillow's ImagingResample 8-bit path, then ToTensor (datasets/utils.py:213-215).  Bit-exact on uint8.
