@@ -778,9 +778,8 @@ class Engine:
         self._wgrad(t, (ws.pf4, None), (n2, h5, w5, 256), t.dz_sq, 'pose_decoder/squeeze', 256, 512, 1, pad=0)
 
     # ------------------------------------------------------------------------------------------
-    # hipGraph: the whole forward+backward of a training step is ~230 kernel launches over three
-    # streams; replaying it as one graph removes the Python/ctypes launch cost (the step is otherwise
-    # host-bound once the kernels take < 5 ms) and keeps the cross-stream concurrency.
+    # hipGraph: the whole forward+backward of a training step (~130 kernel launches over three streams) can be
+    # captured and replayed as one graph.  Kept as an option; see graph_preferred() for why it is not the default.
     GRAPH_KEYS = ([('rgb_aug', f, 0) for f in (-1, 0, 1)] + [('rgb', f, 0) for f in (-1, 0, 1)] +
                   [('rgb', 0, s) for s in (1, 2, 3)] + [('camera_matrix', 0), ('inv_camera_matrix', 0),
                                                         ('relative_distance', 0), ('relative_distance', 1)])
@@ -789,11 +788,11 @@ class Engine:
         return (self.device.type == 'cuda' and os.environ.get('CLSLAM_HIPGRAPH', 'auto') != '0' and ops.PROFILE is None)
 
     def graph_preferred(self, B: int) -> bool:
-        """Measured on MI355X (tools/time_step.py): with B >= 3 the step is GPU-bound and graph replay of the
-        three-stream schedule is no faster than eager launches (4.63 vs 4.51 ms at B=5); small batches are
-        host-bound (~2.2 ms of Python/ctypes launch time per step) and gain.  CLSLAM_HIPGRAPH=1 forces it."""
-        mode = os.environ.get('CLSLAM_HIPGRAPH', 'auto')
-        return self.graphs_enabled() and (mode == '1' or B <= 2)
+        """hipGraph replay of the step is opt-in (CLSLAM_HIPGRAPH=1).  Measured on MI355X / ROCm 7.2: replaying
+        the three-stream step costs 1.73 ms at B=1 and an erratic 2.2-3.6 ms at B=2 (a single-stream capture: 3.4 ms,
+        ~25 us per node) against 1.60 / 1.79 ms for eager launches once the per-launch Python cost was trimmed
+        (raw stream handle, pointer checks); at B >= 3 the step is GPU-bound either way (3.39 vs 4.0 ms)."""
+        return self.graphs_enabled() and os.environ.get('CLSLAM_HIPGRAPH', 'auto') == '1'
 
     def train_step_graphed(self, inputs: Dict[Any, torch.Tensor], *, sample_w: torch.Tensor, smooth_w: Optional[torch.Tensor],
                            noise: Optional[Dict[int, torch.Tensor]], copy_inputs: bool = True,

@@ -12,19 +12,27 @@ from ._lib import ACT_ELU, ACT_HSIGMOID, ACT_HSWISH, ACT_NONE, ACT_RELU, PAD_REF
 PROFILE = None
 
 
-def _stream(t: torch.Tensor):
+# These two helpers run ~1000 times per step; at B <= 2 the step is host-bound, so they avoid every avoidable
+# Python-level call (torch.cuda.current_stream() builds a Stream object: ~2 us each, 200 times per step).
+_raw_stream = torch._C._cuda_getCurrentRawStream if hasattr(torch._C, '_cuda_getCurrentRawStream') else None
+
+
+def _stream(t: torch.Tensor) -> int:
+    """raw hipStream_t of torch's current stream on t's device (0 = the emulator's only stream)"""
     if t.is_cuda:
-        return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
-    return C.c_void_p(0)
+        if _raw_stream is not None:
+            return _raw_stream(t.device.index)
+        return torch.cuda.current_stream(t.device).cuda_stream
+    return 0
 
 
 def _p(t: Optional[torch.Tensor]):
     if t is None:
         return None
-    lib = _lib.get_lib()
-    if t.device.type != lib.device_type:
-        raise _lib.ClslamError(f'tensor on {t.device}, library {lib.path.name} runs on {lib.device_type}')
-    if t.dtype != torch.float32 or not t.is_contiguous():
+    lib = _lib._LIB or _lib.get_lib()
+    if t.is_cuda != lib.is_device or t.dtype is not torch.float32 or not t.is_contiguous():
+        if t.device.type != lib.device_type:
+            raise _lib.ClslamError(f'tensor on {t.device}, library {lib.path.name} runs on {lib.device_type}')
         raise _lib.ClslamError(f'expected contiguous fp32, got {t.dtype} contiguous={t.is_contiguous()}')
     return t.data_ptr()
 
@@ -66,7 +74,7 @@ def conv2d(src_a, weight, out, *, src_b=None, scale=None, shift=None, residual=N
     assert weight.shape[0] == Cout and weight.numel() == Cout * ksize * ksize * (Ca + Cb), weight.shape
     stream = _stream(out)
     if workspace is None and _CONV_WORKSPACES:
-        workspace = _CONV_WORKSPACES.get(stream.value or 0)
+        workspace = _CONV_WORKSPACES.get(stream)
     d = _lib.ConvDesc(_p(src_a), _p(src_b), _p(weight), _p(scale), _p(shift), _p(residual), _p(out),
                       B, Hi, Wi, Ca, Cb, Ho, Wo, Cout, ksize, stride, pad, pad_mode, int(upsample_a), act, config,
                       _p(actgrad_src), actgrad_kind, None if workspace is None else workspace.data_ptr(),
@@ -75,12 +83,12 @@ def conv2d(src_a, weight, out, *, src_b=None, scale=None, shift=None, residual=N
         cfg = config if config >= 0 else _lib.get_lib().cdll.clslam_conv2d_pick_config(C.byref(d))
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        _lib.get_lib().call('clslam_conv2d', C.byref(d), _stream(out))
+        _lib.get_lib().call('clslam_conv2d', C.byref(d), stream)
         e1.record()
         PROFILE.append(('conv_igemm', cfg, 2.0 * B * Ho * Wo * Cout * ksize * ksize * (Ca + Cb), e0, e1,
                         f'B{B} {Hi}x{Wi} {Ca}+{Cb}->{Cout} k{ksize} s{stride} pad{pad}'))
         return out
-    _lib.get_lib().call('clslam_conv2d', C.byref(d), _stream(out))
+    _lib.get_lib().call('clslam_conv2d', C.byref(d), stream)
     return out
 
 

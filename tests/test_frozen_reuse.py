@@ -31,8 +31,10 @@ def _run(B: int, reuse: bool, inject_noise: bool, H: int, W: int, plan=(3, 2)):
 
 
 @pytest.mark.parametrize('backend', BACKENDS)
-@pytest.mark.parametrize('B', [2, 3])               # B=2 takes the hipGraph path on the GPU, B=3 the eager one
-def test_frozen_feature_reuse_is_bitwise_invisible(backend, B):
+@pytest.mark.parametrize('B', [2, 3])               # B=2 forces the hipGraph path on the GPU, B=3 the eager one
+def test_frozen_feature_reuse_is_bitwise_invisible(backend, B, monkeypatch):
+    if B == 2:
+        monkeypatch.setenv('CLSLAM_HIPGRAPH', '1')   # opt-in path: its encoder-free second graph is covered here
     if backend != 'hip' and B == 3:
         pytest.skip('eager path already covered by B=2 on the emulator')
     use_backend(backend)
@@ -76,3 +78,15 @@ def test_reload_voids_held_features(backend):
         next(torch.nn.Module.parameters(p.models['depth_encoder'])).mul_(1.01)
     p.engine.pack_if_needed()
     assert not ws.frozen_valid
+
+
+@pytest.mark.gpu
+def test_hipgraph_replay_matches_eager_launches(monkeypatch):
+    """The opt-in hipGraph path (CLSLAM_HIPGRAPH=1) replays the very launches of the eager path: bitwise equal."""
+    use_backend('hip')
+    monkeypatch.setenv('CLSLAM_HIPGRAPH', '0')
+    ref = _run(2, True, True, H, W)
+    monkeypatch.setenv('CLSLAM_HIPGRAPH', '1')
+    got = _run(2, True, True, H, W)
+    for i, (a, b) in enumerate(zip(ref, got)):
+        assert torch.equal(a, b), i
