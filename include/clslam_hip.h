@@ -271,6 +271,20 @@ typedef struct clslam_copy_item {
 int clslam_copy_multi(const clslam_copy_item* items, int nitems, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Exact inner-product search = what the reference asks of faiss's
+ * index_factory(d, 'Flat', METRIC_INNER_PRODUCT): loop_closure_detection/loop_closure_detection.py:35-36
+ * (.add :48, .reconstruct/.search(features, 100) :55-57) and slam/replay_buffer.py:96-98 (.search(f, 1) :110,
+ * .search(features, ntotal) :121-122,130).  Rows are L2-normalised by the caller (faiss.normalize_L2).
+ * clslam_ip_scores: scores[q][i] = <db[i], queries[q]>, db (n,d) / queries (nq,d) / scores (nq,n) row-major.
+ * clslam_topk_desc: the k largest per query in descending order, equal scores by ascending position;
+ * out_val/out_idx (nq,k), missing entries -FLT_MAX / -1 like faiss.  n > 4096 needs cand_val/cand_idx of
+ * nq * clslam_topk_chunks(n) * k elements (and chunks * k <= 4096).                                  */
+int clslam_ip_scores(const float* db, const float* queries, float* scores, int n, int d, int nq, void* stream);
+int clslam_topk_chunks(int n);
+int clslam_topk_desc(const float* scores, int n, int nq, int k, float* cand_val, int* cand_idx, float* out_val,
+                     int* out_idx, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Image-pyramid ingest: the reference's datasets resize every pyramid level from the
  * previous one with torchvision.transforms.Resize(LANCZOS) on PIL images (datasets/utils.py:62-66,154-163)
  * = Pillow's ImagingResample 8-bit path, then ToTensor (datasets/utils.py:213-215).  Bit-exact on uint8.
