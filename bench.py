@@ -17,8 +17,8 @@ grows ("weak").  `--total-replay K` instead shards a minibatch of 1+K triplets a
 (1+R) triplets: value = steps/s * B/(1+R), so N = 1 is plain frames/s.
 
 Rank 0 prints ONE JSON line (contract in the task description) with `roofline` (dominant kernel:
-the fp32-MFMA implicit-GEMM conv, algorithmic FLOPs / HIP-event launch time vs the 157.3 TFLOP/s
-fp32 matrix peak) and `cpu_baseline` (the oracle's torch-CPU restatement of the same step, timed on
+the fp32-MFMA conv, algorithmic FLOPs / the launches' own start-stop HIP events -- hipExtLaunchKernel
+timestamps taken by the library, the duration rocprofv3 reports -- vs the 157.3 TFLOP/s fp32 matrix peak) and `cpu_baseline` (the oracle's torch-CPU restatement of the same step, timed on
 this box's host cores on a bounded sample).
 """
 import argparse
@@ -169,19 +169,18 @@ def main():
         p.engine.use_side_stream = False
         step()
         torch.cuda.synchronize()
-        ops.PROFILE = []
+        ops.profile_begin()
         step()
         torch.cuda.synchronize()
         agg = {}
-        for kind, cfg, flops, e0, e1, desc in ops.PROFILE:
+        for kind, cfg, flops, secs, desc in ops.profile_end():
             if args.dump_convs:
-                us = e0.elapsed_time(e1) * 1e3
+                us = secs * 1e6
                 print(f'# conv cfg{cfg:3d} {desc:40s} {flops / 1e9:7.2f} GF {us:8.1f} us {flops / us / 1e6:6.1f} TF', file=sys.stderr)
             a = agg.setdefault((kind, cfg), [0.0, 0.0, 0])
             a[0] += flops
-            a[1] += e0.elapsed_time(e1) * 1e-3
+            a[1] += secs
             a[2] += 1
-        ops.PROFILE = None
         p.engine.use_side_stream = True
         # kernel names as rocprofv3 prints them (template arguments TH, TW, BN, BK, MF, WGM, RUN, LDPAD, S, SK)
         patch = {10: '8, 16, 64, 16, 32, 2, false, 4, 1', 11: '8, 16, 32, 16, 32, 4, false, 4, 1', 12: '8, 16, 16, 16, 16, 4, false, 4, 1',

@@ -111,6 +111,8 @@ _SIGNATURES = {
                          fptr, C.c_void_p],
     'clslam_disp_grad': [fptr, fptr, fptr, i32, fptr, i32, i32, i32, i32, i32, C.c_void_p],
     'clslam_copy_multi': [C.c_void_p, i32, C.c_void_p],
+    'clslam_conv_profile_begin': [i32],
+    'clslam_conv_profile_end': [C.c_void_p, i32, C.c_void_p],
     'clslam_ip_scores': [fptr, fptr, fptr, i32, i32, i32, C.c_void_p],
     'clslam_topk_chunks': [i32],
     'clslam_topk_desc': [fptr, i32, i32, i32, fptr, C.c_void_p, fptr, C.c_void_p, C.c_void_p],

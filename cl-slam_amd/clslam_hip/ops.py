@@ -8,8 +8,32 @@ from . import _lib
 from ._lib import ACT_ELU, ACT_HSIGMOID, ACT_HSWISH, ACT_NONE, ACT_RELU, PAD_REFLECT, PAD_ZERO  # noqa: F401
 
 
-# bench.py sets this to a list to collect (kernel, tile config, algorithmic flops, start, end) per conv launch
+# profile_begin() sets this to a list collecting (kind, tile config, algorithmic flops, description) per conv launch
 PROFILE = None
+
+
+def profile_begin(max_launches: int = 8192) -> None:
+    """Measurement (bench.py's roofline leg): every conv2d() launch from now on is timestamped by the library itself
+    (clslam_conv_profile_begin: kernel start/stop, the duration rocprofv3 reports).  Run the launches in serial order
+    (engine.use_side_stream = False): concurrent kernels share the GPU and a launch's duration says little then."""
+    global PROFILE
+    _lib.get_lib().call('clslam_conv_profile_begin', max_launches)
+    PROFILE = []
+
+
+def profile_end():
+    """-> [(kind, config, flops, seconds, description)] in launch order; disarms."""
+    global PROFILE
+    meta, PROFILE = PROFILE, None
+    cap = max(1, len(meta))
+    ms = (C.c_float * cap)()
+    count = C.c_int(0)
+    _lib.get_lib().call('clslam_conv_profile_end', C.cast(ms, C.c_void_p), cap, C.cast(C.pointer(count), C.c_void_p))
+    if not _lib.get_lib().is_device:      # the emulator build has no timestamps
+        return [(k, cfg, fl, 0.0, desc) for k, cfg, fl, desc in meta]
+    if count.value != len(meta):
+        raise _lib.ClslamError(f'profile_end: {count.value} timed launches for {len(meta)} conv2d calls')
+    return [(k, cfg, fl, ms[i] * 1e-3, desc) for i, (k, cfg, fl, desc) in enumerate(meta)]
 
 
 # These two helpers run ~1000 times per step; at B <= 2 the step is host-bound, so they avoid every avoidable
@@ -79,15 +103,10 @@ def conv2d(src_a, weight, out, *, src_b=None, scale=None, shift=None, residual=N
                       B, Hi, Wi, Ca, Cb, Ho, Wo, Cout, ksize, stride, pad, pad_mode, int(upsample_a), act, config,
                       _p(actgrad_src), actgrad_kind, None if workspace is None else workspace.data_ptr(),
                       0 if workspace is None else workspace.numel())
-    if PROFILE is not None:
+    if PROFILE is not None:     # armed by profile_begin(): the library timestamps the launch itself
         cfg = config if config >= 0 else _lib.get_lib().cdll.clslam_conv2d_pick_config(C.byref(d))
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        _lib.get_lib().call('clslam_conv2d', C.byref(d), stream)
-        e1.record()
-        PROFILE.append(('conv_igemm', cfg, 2.0 * B * Ho * Wo * Cout * ksize * ksize * (Ca + Cb), e0, e1,
+        PROFILE.append(('conv', cfg, 2.0 * B * Ho * Wo * Cout * ksize * ksize * (Ca + Cb),
                         f'B{B} {Hi}x{Wi} {Ca}+{Cb}->{Cout} k{ksize} s{stride} pad{pad}'))
-        return out
     _lib.get_lib().call('clslam_conv2d', C.byref(d), stream)
     return out
 

@@ -3,6 +3,8 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <utility>
+#include <vector>
 
 namespace clslam {
 
@@ -24,7 +26,54 @@ int check_launch(const char* what) {
     return CLSLAM_OK;
 }
 
+// ---- kernel-exact conv timing (measurement only) ---------------------------------------------
+static thread_local std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof;
+static thread_local int g_prof_cap = 0;   // 0: not armed
+
+bool profile_next_events(hipEvent_t* start, hipEvent_t* stop) {
+#if CLSLAM_DEVICE_BUILD
+    if (g_prof_cap <= 0 || (int)g_prof.size() >= g_prof_cap) return false;
+    hipEvent_t a = nullptr, b = nullptr;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return false;
+    g_prof.emplace_back(a, b);
+    *start = a; *stop = b;
+    return true;
+#else
+    (void)start; (void)stop;
+    return false;
+#endif
+}
+
 }  // namespace clslam
+
+extern "C" int clslam_conv_profile_begin(int max_launches) {
+    CLSLAM_REQUIRE(max_launches > 0, "conv_profile_begin: max_launches must be positive");
+    CLSLAM_REQUIRE(clslam::g_prof_cap == 0, "conv_profile_begin: already armed on this thread");
+    clslam::g_prof.clear();
+    clslam::g_prof_cap = max_launches;
+    return CLSLAM_OK;
+}
+
+extern "C" int clslam_conv_profile_end(float* ms, int capacity, int* count) {
+    CLSLAM_REQUIRE(count && (ms || capacity == 0), "conv_profile_end: null");
+    clslam::g_prof_cap = 0;
+    int n = 0, rc = CLSLAM_OK;
+#if CLSLAM_DEVICE_BUILD
+    for (auto& ev : clslam::g_prof) {
+        float t = 0.f;
+        if (hipEventSynchronize(ev.second) != hipSuccess || hipEventElapsedTime(&t, ev.first, ev.second) != hipSuccess) {
+            clslam::set_error("conv_profile_end: %s", hipGetErrorString(hipGetLastError()));
+            rc = CLSLAM_ERR_LAUNCH;
+        }
+        if (n < capacity) ms[n] = t;
+        ++n;
+        hipEventDestroy(ev.first); hipEventDestroy(ev.second);
+    }
+#endif
+    clslam::g_prof.clear();
+    *count = n;
+    return rc;
+}
 
 extern "C" int clslam_version(void) { return 100; }
 extern "C" const char* clslam_last_error(void) { return clslam::g_err; }

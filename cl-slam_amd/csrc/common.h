@@ -1,6 +1,9 @@
 // Shared declarations for the clslam HIP kernels (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#if CLSLAM_DEVICE_BUILD
+#include <hip/hip_ext.h>
+#endif
 #include <clslam/intrin.h>
 
 #include <algorithm>
@@ -52,5 +55,22 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 }
 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// Measurement hook (clslam_conv_profile_begin/end, bench.py's roofline leg): while armed, every conv launch of
+// this host thread carries its own start/stop events, i.e. the kernel's execution time as rocprofv3 reports it
+// (an event pair recorded AROUND a launch also counts the dispatch gap, ~3 us).  False when not armed.
+bool profile_next_events(hipEvent_t* start, hipEvent_t* stop);
+
+template <typename F, typename Arg>
+inline void conv_launch(F kernel, int nblk, hipStream_t stream, const Arg& k) {
+#if CLSLAM_DEVICE_BUILD
+    hipEvent_t e0, e1;
+    if (profile_next_events(&e0, &e1)) {
+        hipExtLaunchKernelGGL(kernel, dim3(nblk), dim3(256), 0, stream, e0, e1, 0, k);
+        return;
+    }
+#endif
+    hipLaunchKernelGGL(kernel, dim3(nblk), dim3(256), 0, stream, k);
+}
 
 }  // namespace clslam

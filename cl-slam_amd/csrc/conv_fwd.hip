@@ -221,7 +221,7 @@ static int launch_conv(ConvK k, hipStream_t stream) {
     k.tilesM = cdiv(k.M, BM);
     k.tilesN = cdiv(k.Cout, BN);
     k.nblk = k.tilesM * k.tilesN;
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, MF, WGM>), dim3(k.nblk), dim3(256), 0, stream, k);
+    conv_launch(conv_igemm_kernel<BM, BN, BK, MF, WGM>, k.nblk, stream, k);
     return check_launch("conv_igemm");
 }
 

@@ -364,11 +364,11 @@ static int launch_patch(PatchK k, hipStream_t stream) {
     if (const char* e = getenv("CLSLAM_N_FASTEST")) k.n_fastest = atoi(e);
     if constexpr (SKOK) {
         if (ksplit > 1) {
-            hipLaunchKernelGGL((conv3x3_patch_kernel<TH, TW, BN, BK, MF, WGM, RUN, LDPAD, S, true>), dim3(k.nblk), dim3(256), 0, stream, k);
+            conv_launch(conv3x3_patch_kernel<TH, TW, BN, BK, MF, WGM, RUN, LDPAD, S, true>, k.nblk, stream, k);
             return check_launch("conv3x3_patch(split-K)");
         }
     }
-    hipLaunchKernelGGL((conv3x3_patch_kernel<TH, TW, BN, BK, MF, WGM, RUN, LDPAD, S, false>), dim3(k.nblk), dim3(256), 0, stream, k);
+    conv_launch(conv3x3_patch_kernel<TH, TW, BN, BK, MF, WGM, RUN, LDPAD, S, false>, k.nblk, stream, k);
     return check_launch("conv3x3_patch");
 }
 

@@ -259,6 +259,15 @@ int clslam_adam_step(float* param, const float* grad, float* exp_avg, float* exp
                      double beta1, double beta2, double eps, int step, float grad_scale, const float* guard, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Measurement hook (bench.py's roofline leg; no reference counterpart).  Between _begin and _end every
+ * clslam_conv2d launch issued by THIS host thread carries its own start/stop timestamps (hipExtLaunchKernel):
+ * the kernel's execution time, the quantity `rocprofv3 --kernel-trace` reports -- an event pair recorded around
+ * a launch also counts the ~3 us dispatch gap.  _end waits for the launches, writes their durations in
+ * milliseconds in launch order (at most `capacity`), stores how many there were in *count and disarms.   */
+int clslam_conv_profile_begin(int max_launches);
+int clslam_conv_profile_end(float* ms, int capacity, int* count);
+
+/* ---------------------------------------------------------------------------------------------
  * nitems independent device-to-device copies in one launch (items is a HOST array; sizes in bytes,
  * any alignment).  No reference counterpart: it replaces the per-tensor copies a hipGraph-replayed
  * step needs around the replay -- the sample dict of dpp.py:916-917 into the graph's static inputs and

@@ -23,6 +23,7 @@ extern thread_local emu_uint3 threadIdx, blockIdx;
 extern thread_local dim3 blockDim, gridDim;
 
 typedef void* hipStream_t;
+typedef void* hipEvent_t;
 typedef int hipError_t;
 enum { hipSuccess = 0 };
 inline hipError_t hipGetLastError() { return hipSuccess; }

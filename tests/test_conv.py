@@ -144,3 +144,25 @@ def test_conv2d_split_k(backend, case, monkeypatch):
     assert torch.equal(outs[0], outs[1])
     assert rel_err(outs[0], outs[2]) < 1e-5 and not torch.equal(outs[0], outs[2])   # split really happened
     assert int(ws[:65536].view(torch.int32).abs().sum()) == 0
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_conv_profile_hook_times_every_launch(backend):
+    """clslam_conv_profile_begin/end (bench.py's roofline leg): one kernel-exact duration per conv2d launch, in order."""
+    dev = use_backend(backend)
+    x = torch.randn(2, 12, 20, 32, device=dev)
+    w = torch.randn(64, 9, 32, device=dev) * 0.1
+    w1 = torch.randn(64, 1, 32, device=dev) * 0.1
+    out = torch.empty(2, 12, 20, 64, device=dev)
+    ops.profile_begin()
+    ops.conv2d(x, w, out, ksize=3)
+    ops.conv2d(x, w1, out, ksize=1, pad=0)
+    ops.conv2d(x, w, out, ksize=3, config=21)
+    got = ops.profile_end()
+    assert ops.PROFILE is None and len(got) == 3
+    assert [g[2] for g in got] == [2.0 * 480 * 64 * 9 * 32, 2.0 * 480 * 64 * 32, 2.0 * 480 * 64 * 9 * 32]
+    assert got[2][1] == 21
+    if backend == 'hip':
+        assert all(1e-7 < g[3] < 1e-2 for g in got), got
+    ops.conv2d(x, w, out, ksize=3)          # disarmed again: plain launches
+    ops.profile_begin(); assert ops.profile_end() == []
