@@ -159,6 +159,25 @@ def main():
     ms = dt / args.steps * 1e3
     value = (args.steps / dt) * (B / FRAME_TRIPLETS)
 
+    also = None
+    if N == 1 and S == 1 and not args.no_also:
+        # the reference's shipped configuration (config_adapt.yaml:53, adaptation_epochs: 5): five optimizer steps
+        # per incoming frame; steps 2..5 keep the frozen encoders' features (engine.forward reuse_frozen).
+        # Best of three groups of six calls (a reported extra, not the headline: one noisy group should not move it).
+        for _ in range(2):
+            p.adapt(None, batch, steps=5)
+        groups = []
+        for _ in range(3):
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(6):
+                p.adapt(None, batch, steps=5)
+            sync()
+            groups.append((time.perf_counter() - t0) / 6 * 1e3)
+        ms5 = min(groups)
+        also = {'adapt_steps_per_frame': 5, 'ms_per_frame': round(ms5, 3), 'frames_per_s': round(1e3 / ms5, 2),
+                'ms_per_optimizer_step': round(ms5 / 5, 3)}
+
     # ---- roofline of the dominant kernel (instrumented extra step, outside the timed region) ------
     roof = None
     if rank != 0 and N > 1:
@@ -208,20 +227,6 @@ def main():
                 'avg_launch_us': round(tt / cnt * 1e6, 2), 'flops_per_launch_avg': fl / cnt,
                 'all_conv_launches': {'achieved': round(all_fl / all_t / 1e12, 2), 'time_ms_per_step': round(all_t * 1e3, 3),
                                       'gflop_per_step': round(all_fl / 1e9, 2)}}
-    also = None
-    if N == 1 and S == 1 and not args.no_also:
-        # the reference's shipped configuration (config_adapt.yaml:53, adaptation_epochs: 5): five optimizer steps
-        # per incoming frame; steps 2..5 keep the frozen encoders' features (engine.forward reuse_frozen)
-        for _ in range(2):
-            p.adapt(None, batch, steps=5)
-        sync()
-        t0 = time.perf_counter()
-        for _ in range(10):
-            p.adapt(None, batch, steps=5)
-        sync()
-        ms5 = (time.perf_counter() - t0) / 10 * 1e3
-        also = {'adapt_steps_per_frame': 5, 'ms_per_frame': round(ms5, 3), 'frames_per_s': round(1e3 / ms5, 2),
-                'ms_per_optimizer_step': round(ms5 / 5, 3)}
     cpu = None
     if rank == 0 and N == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(H, W, B)
