@@ -40,8 +40,9 @@ def test_frozen_feature_reuse_is_bitwise_invisible(backend, B, monkeypatch):
     use_backend(backend)
     h, w = _size(backend)
     plan = (3, 2) if backend == 'hip' else (2, 1)
-    ref = _run(B, False, True, h, w, plan)
-    got = _run(B, True, True, h, w, plan)
+    n = B if backend == 'hip' else 1                 # emulator: one sample keeps the CPU suite short
+    ref = _run(n, False, True, h, w, plan)
+    got = _run(n, True, True, h, w, plan)
     for i, (a, b) in enumerate(zip(ref, got)):
         assert torch.equal(a, b), i
 
@@ -56,7 +57,7 @@ def test_reuse_actually_skips_the_encoders(backend, monkeypatch):
     orig = p.engine._encoder
     monkeypatch.setattr(p.engine, '_encoder', lambda *a, **k: (calls.append(1), orig(*a, **k))[1])
     monkeypatch.setattr(p.engine, 'graph_preferred', lambda B: False)
-    p.adapt(None, synth.make_batch(n, H, W, seed=3), steps=3)
+    p.adapt(None, synth.make_batch(n, H, W, seed=3), steps=3 if backend == 'hip' else 2)
     assert len(calls) == 2                           # depth + pose encoder, first step only
     p.adapt(None, synth.make_batch(n, H, W, seed=4), steps=1)
     assert len(calls) == 4                           # a new call never reuses
