@@ -378,6 +378,11 @@ class Engine:
 
     def _depth_decoder(self, ws, feats: List[torch.Tensor]) -> None:
         x = feats[4]
+        # the disparity heads of scales 3..1 are leaves of the chain (only the view synthesis reads them): they go to
+        # the wgrad stream, idle during the forward, instead of sitting between two convolutions of the chain
+        main = torch.cuda.current_stream(self.device) if self.device.type == 'cuda' else None
+        leaf = self.wg_stream if (main is not None and self.use_side_stream and self.wg_stream is not None) else None
+        forked = False
         for i in range(4, -1, -1):
             cin0 = NUM_CH_ENC[-1] if i == 4 else NUM_CH_DEC[i + 1]
             w, b = self._wb(f'depth_decoder/upconv_{i}_0.conv.conv', NUM_CH_DEC[i], cin0, 9)
@@ -390,7 +395,17 @@ class Engine:
             x = ws.x[i, 1]
             if i <= 3:
                 w, b = self._wb(f'depth_decoder/dispconv_{i}.conv', 1, NUM_CH_DEC[i], 9)
-                ops.dispconv_fwd(x, w.view(9, NUM_CH_DEC[i]), b, ws.disp[i])
+                if leaf is not None and i > 0:
+                    ev = torch.cuda.Event()
+                    ev.record(main)
+                    leaf.wait_event(ev)
+                    with torch.cuda.stream(leaf):
+                        ops.dispconv_fwd(x, w.view(9, NUM_CH_DEC[i]), b, ws.disp[i])
+                    forked = True
+                else:
+                    ops.dispconv_fwd(x, w.view(9, NUM_CH_DEC[i]), b, ws.disp[i])
+        if forked:
+            main.wait_stream(leaf)
 
     def _pose_decoder(self, ws, f4: torch.Tensor) -> None:
         w, b = self._wb('pose_decoder/squeeze', 256, 512, 1)
