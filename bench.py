@@ -93,6 +93,8 @@ def main():
                     'S=1, the reference\'s config_adapt.yaml runs S=5')
     ap.add_argument('--height', type=int, default=192)
     ap.add_argument('--width', type=int, default=640)
+    ap.add_argument('--random-images', action='store_true', help='uniform-random image content instead of the smooth synthetic '
+                    'frames (SURVEY.md 8d: the photometric min / mask then flips per pixel -- worst case for the loss stage)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-also', action='store_true', help='skip the extra adapt(steps=5) timing (profiling runs)')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo lets two '
@@ -128,10 +130,16 @@ def main():
     Bl = counts[rank]
 
     from clslam_hip import ops, synth
+    torch.manual_seed(1 + rank)          # the tie-break noise is drawn on the device: same trajectory every run
     p = build_predictor(H, W, B if N == 1 else Bl)
     if N > 1:
         p.enable_data_parallel(B, offset)
     full = synth.make_batch(B, H, W, seed=0)
+    if args.random_images:
+        g = torch.Generator().manual_seed(1234)
+        for k in list(full):
+            if k[0] in ('rgb', 'rgb_aug'):
+                full[k] = torch.rand(full[k].shape, generator=g)
     batch = {k: v[offset:offset + Bl].to(dev) for k, v in full.items()}
 
     S = args.adapt_steps
@@ -235,7 +243,7 @@ def main():
             'metric': 'online-adapt frames/sec @192x640 (1 triplet + K replay)',
             'value': round(value, 3), 'unit': 'frames/s', 'n_gpus': N, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32', 'data': 'synthetic',
+            'dtype': 'f32', 'data': 'synthetic (uniform-random images)' if args.random_images else 'synthetic',
             'config': {'workload': f'DepthPosePrediction.adapt(steps={S}), {H}x{W}, 1 online + K={K} replay triplets '
                                    f'(global batch {B}); ResNet-18 depth+pose nets, closed-form random-init weights; '
                                    f'a frame = {FRAME_TRIPLETS} triplets (value = steps/s * B/{FRAME_TRIPLETS})',
