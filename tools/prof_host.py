@@ -1,5 +1,8 @@
+"""cProfile of the host side of 50 eager adapt steps at B=1 (where the step is closest to host-bound)."""
 import cProfile, pstats, sys, os, io
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/cl-slam_amd')
+from pathlib import Path
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / 'cl-slam_amd'))
 os.environ['CLSLAM_HIPGRAPH'] = '0'
 import torch, bench
 from clslam_hip import synth
