@@ -112,3 +112,34 @@ def test_nan_loss_aborts_without_update(backend):
     p.adapt(None, {k: v.clone() for k, v in batch.items()}, steps=1)      # and the predictor is still usable
     assert p.engine.adam_step_count == count0 + 1
     assert not torch.equal(p.engine.w, w0)
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_uniform_random_image_content_matches_oracle(backend):
+    """SURVEY.md 8d's second input family: uniform-random pixels instead of the smooth synthetic frames -- the
+    4-way photometric min then changes winner from pixel to pixel (auto-mask, argmin planes and their gradients
+    at their busiest).  Forward quantities of the step are held to the same 1e-4 as on the smooth frames."""
+    use_backend(backend)
+    B = 2
+    p = make_predictor(H, W, B)
+    o = make_oracle(H, W, B)
+    batch = synth.make_batch(B, H, W, seed=33)
+    g = torch.Generator().manual_seed(1234)
+    for k in list(batch):
+        if k[0] in ('rgb', 'rgb_aug'):
+            batch[k] = torch.rand(batch[k].shape, generator=g)
+    noise = synth.make_noise(B, H, W, seed=6)
+    p.set_tie_break_noise(noise)
+    out, losses = p.adapt(None, {k: v.clone() for k, v in batch.items()}, steps=1)
+    o.set_adapt()
+    oo, ol = o.process_batch(batch, noise, None)
+    assert rel_err(out['depth', 0].cpu(), oo['depth', 0].detach()) < 1e-4
+    assert rel_err(out['cam_T_cam', 0, 1].cpu(), oo['cam_T_cam', 0, 1].detach()) < 1e-4
+    # A warped image of white noise has unit gradient per pixel, and the untrained pose net's large translations turn a
+    # 1e-5 relative depth difference into ~3e-4 px of parallax: the synthesised frames are compared at 2e-3 of full
+    # scale here (2e-5 on the smooth frames, tests/test_loss_stage.py); the per-sample means that make up the losses
+    # average that away.
+    for s in range(4):
+        assert rel_err(out['rgb', -1, s].cpu(), oo['rgb', -1, s].detach()) < 2e-3
+    for k, v in ol.items():
+        assert abs(float(losses[k]) - float(v)) <= 1e-4 * max(abs(float(v)), 1e-3), k
