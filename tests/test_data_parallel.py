@@ -1,4 +1,5 @@
-"""Data-parallel replay minibatch: B triplets sharded over R ranks == single rank,
+"""Data-parallel replay minibatch: B triplets sharded over R ranks == single rank, over two steps of
+one adapt() call (the second one on the frozen-feature reuse path),
 incl. the sample-0 smoothness behaviour living on rank 0.  Runs on CPU: gloo, world_size 2, the
 kernels through the emulator build (the GPU path differs only by backend 'nccl' = RCCL)."""
 import os
@@ -31,7 +32,7 @@ def _worker(rank, world, port, counts, out_dir):
     noise = synth.make_noise(B, H, W, seed=8)
     p.set_tie_break_noise({s: v[off:off + counts[rank]] for s, v in noise.items()})
     batch = {k: v[off:off + counts[rank]].clone() for k, v in full.items()}
-    out, losses = p.adapt(None, batch, steps=1)
+    out, losses = p.adapt(None, batch, steps=2)      # second step: frozen-feature reuse under data parallelism
     everything = p.gather_outputs(out)               # uneven shards (2 + 1)
     in_sync = p.replicas_in_sync()
     if rank == 1:                                    # a single flipped mantissa bit on one rank must be noticed
@@ -55,7 +56,7 @@ def test_two_ranks_equal_single_rank(tmp_path):
     p = make_predictor(H, W, B)
     p.set_tie_break_noise(synth.make_noise(B, H, W, seed=8))
     full = synth.make_batch(B, H, W, seed=4)
-    out, losses = p.adapt(None, {k: v.clone() for k, v in full.items()}, steps=1)
+    out, losses = p.adapt(None, {k: v.clone() for k, v in full.items()}, steps=2)
     counts = [2, 1]
     port = 29500 + (os.getpid() % 2000)
     mp.start_processes(_worker, args=(2, port, counts, str(tmp_path)), nprocs=2, join=True, start_method='spawn')
@@ -65,15 +66,16 @@ def test_two_ranks_equal_single_rank(tmp_path):
     assert torch.equal(r0['g'], r1['g']) and torch.equal(r0['w'], r1['w'])
     # equal to the single-rank run up to summation order
     g = p.engine.g
-    assert float((r0['g'] - g).abs().max() / g.abs().max()) < 1e-5
+    # (second step: the weights already differ by the summation order of step 1, so does this gradient)
+    assert float((r0['g'] - g).abs().max() / g.abs().max()) < 1e-4
     assert float((r0['w'] - p.engine.w).abs().max()) < 0.3e-4          # well below one lr-sized flip
     for k, v in losses.items():
-        assert abs(float(r0['loss'][k]) - float(v)) <= 2e-6 * max(abs(float(v)), 1e-3), k
-    assert torch.allclose(r0['T'], out['cam_T_cam', 0, 1][:2], atol=1e-7)
+        assert abs(float(r0['loss'][k]) - float(v)) <= 2e-5 * max(abs(float(v)), 1e-3), k   # losses of the 2nd step
+    assert torch.allclose(r0['T'], out['cam_T_cam', 0, 1][:2], atol=1e-6)
     # the explicit all-gather helper: the single-process full-batch dict, identical on both ranks
     for r in (r0, r1):
         assert r['in_sync'] and r['diverged_seen']
         assert r['full_depth'].shape == out['depth', 0].shape
         assert torch.equal(r['full_depth'], r0['full_depth'])
-        assert torch.allclose(r['full_depth'], out['depth', 0], rtol=1e-6, atol=0)
-        assert torch.allclose(r['full_T'], out['cam_T_cam', 0, -1], atol=1e-7)
+        assert torch.allclose(r['full_depth'], out['depth', 0], rtol=1e-5, atol=0)
+        assert torch.allclose(r['full_T'], out['cam_T_cam', 0, -1], atol=1e-6)
