@@ -116,6 +116,9 @@ _SIGNATURES = {
     'clslam_ip_scores': [fptr, fptr, fptr, i32, i32, i32, C.c_void_p],
     'clslam_topk_chunks': [i32],
     'clslam_topk_desc': [fptr, i32, i32, i32, fptr, C.c_void_p, fptr, C.c_void_p, C.c_void_p],
+    'clslam_l2_normalize_rows': [fptr, i32, i32, C.c_void_p],
+    'clslam_diversity_commit': [fptr, fptr, i32, C.c_void_p, i32, i32, i32, i32, C.c_float, fptr, fptr, C.c_void_p,
+                                fptr, C.c_void_p],
 }
 _RESTYPES = {'clslam_last_error': C.c_char_p}
 

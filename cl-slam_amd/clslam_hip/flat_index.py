@@ -21,13 +21,20 @@ from . import _lib, ops
 FLT_MAX = float(np.finfo(np.float32).max)
 
 
-def normalize_L2(x: np.ndarray) -> None:
-    """faiss.normalize_L2: rows of a C-contiguous float32 matrix scaled to unit L2 norm in place (zero rows stay)."""
+def normalize_L2(x) -> None:
+    """faiss.normalize_L2 (fvec_renorm_L2): every row multiplied by 1/sqrt(<row,row>) in place, zero rows stay.
+    A C-contiguous float32 numpy matrix is normalised on the host (what the reference hands over); a device tensor
+    by clslam_l2_normalize_rows."""
+    if isinstance(x, torch.Tensor):
+        if not (x.dtype == torch.float32 and x.dim() == 2 and x.is_contiguous()):
+            raise TypeError('normalize_L2 needs a contiguous float32 matrix')
+        _lib.get_lib().call('clslam_l2_normalize_rows', x.data_ptr(), x.shape[0], x.shape[1], ops._stream(x))
+        return
     if not (isinstance(x, np.ndarray) and x.dtype == np.float32 and x.ndim == 2 and x.flags.c_contiguous):
         raise TypeError('normalize_L2 needs a C-contiguous float32 matrix')
-    nrm = np.sqrt((x.astype(np.float32) ** 2).sum(axis=1, dtype=np.float32))
-    nz = nrm > 0
-    x[nz] /= nrm[nz, None]
+    nrm2 = (x * x).sum(axis=1, dtype=np.float32)
+    nz = nrm2 > 0
+    x[nz] *= (np.float32(1.0) / np.sqrt(nrm2[nz]))[:, None]
 
 
 class FlatIPIndex:
@@ -73,16 +80,28 @@ class FlatIPIndex:
     def reconstruct(self, i: int) -> np.ndarray:
         if not 0 <= i < self.ntotal:
             raise IndexError(i)
-        return self._db[i].cpu().numpy()
+        return self._db[i].cpu().numpy().copy()
 
     def reconstruct_n(self, i0: int, n: int) -> np.ndarray:
         if i0 < 0 or n < 0 or i0 + n > self.ntotal:
             raise IndexError((i0, n))
-        return self._db[i0:i0 + n].cpu().numpy()
+        return self._db[i0:i0 + n].cpu().numpy().copy()
+
+    def row(self, i: int) -> torch.Tensor:
+        """stored vector i as a device view (no host copy; what `reconstruct` returns after a D2H)"""
+        if not 0 <= i < self.ntotal:
+            raise IndexError(i)
+        return self._db[i]
 
     def remove_ids(self, ids) -> int:
         """Drop every stored vector whose id is listed; the others keep their order (IndexFlat compaction)."""
-        keep = ~np.isin(self._ids, np.asarray(ids, dtype=np.int64).reshape(-1))
+        return self.remove_where(np.isin(self._ids, np.asarray(ids, dtype=np.int64).reshape(-1)))
+
+    def remove_where(self, drop: np.ndarray) -> int:
+        """Drop the storage positions flagged in the boolean vector `drop` (length ntotal), order kept."""
+        keep = ~np.asarray(drop, dtype=bool).reshape(-1)
+        if keep.shape[0] != self.ntotal:
+            raise ValueError('one flag per stored vector')
         removed = int((~keep).sum())
         if removed:
             sel = torch.from_numpy(np.nonzero(keep)[0]).to(self.device)
@@ -93,6 +112,15 @@ class FlatIPIndex:
         return removed
 
     # -- search ----------------------------------------------------------------------------------------
+    def scores(self, x) -> torch.Tensor:
+        """(nq, ntotal) inner products on the device, storage order (no top-k, no host copy)."""
+        q = self._as_rows(x)
+        out = torch.empty(q.shape[0], self.ntotal, device=self.device)
+        if q.shape[0] and self.ntotal:
+            _lib.get_lib().call('clslam_ip_scores', self._db.data_ptr(), q.data_ptr(), out.data_ptr(), self.ntotal, self.d,
+                                q.shape[0], ops._stream(out))
+        return out
+
     def search(self, x, k: int) -> Tuple[np.ndarray, np.ndarray]:
         q = self._as_rows(x)
         nq, n, k = q.shape[0], self.ntotal, int(k)

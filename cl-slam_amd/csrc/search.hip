@@ -90,6 +90,138 @@ __global__ __launch_bounds__(256) void topk_sort_kernel(const float* __restrict_
     }
 }
 
+
+// faiss.normalize_L2 (fvec_renorm_L2): x_i *= 1/sqrt(<x_i,x_i>) for rows with a non-zero norm.  One wave per row.
+__global__ __launch_bounds__(256) void l2_normalize_kernel(float* __restrict__ x, int n, int d) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wave;              // wave-uniform
+    if (row >= n) return;
+    float* r = x + (size_t)row * d;
+    float acc = 0.f;
+    for (int i = lane; i < d; i += 64) acc = fmaf(r[i], r[i], acc);
+    acc = wave_sum(acc);
+    if (!(acc > 0.f)) return;
+    const float inv = 1.0f / sqrtf(acc);
+    for (int i = lane; i < d; i += 64) r[i] *= inv;
+}
+
+// The replay buffer's diversity bookkeeping (slam/replay_buffer.py:104-152) for one candidate, in ONE workgroup:
+// the similarity matrix S of the stored samples lives in HBM in SLOT order (a freed slot is re-used by the next
+// accepted sample, exactly the reference's `fill_up_index`), so nothing is ever compacted or rebuilt.
+//   scores[j] = <db[j], q> for every slot j < nslots (clslam_ip_scores ran before this launch)
+//   1. similarity = max over occupied slots (0 when the buffer is empty, replay_buffer.py:107-110)
+//   2. similarity < threshold: q goes to the first free slot (or slot nslots), row/column of S are its scores,
+//      S[slot][slot] = <q,q>                                                (replay_buffer.py:112-139)
+//   3. more than `capacity` samples now: evict argmax_j (sum_i S[i][j] - S[j][j]), the sample most similar to
+//      all others (first maximum, column sums added in slot order like numpy's sum(0))   (replay_buffer.py:141-150)
+// result: [0]=accepted, [1]=slot written (-1), [2]=slot evicted (-1), [3]=occupied slots afterwards; sim_out[0].
+__global__ __launch_bounds__(256) void diversity_commit_kernel(float* __restrict__ db, float* __restrict__ S, int ld,
+                                                               unsigned char* __restrict__ occupied, int nslots, int max_slots,
+                                                               int d, int capacity, float threshold,
+                                                               const float* __restrict__ q, const float* __restrict__ scores,
+                                                               int* __restrict__ result, float* __restrict__ sim_out) {
+    __shared__ float red_v[256];
+    __shared__ int red_i[256];
+    __shared__ int sh_slot, sh_count;
+    const int tid = threadIdx.x;
+    // 1. nearest stored sample; first free slot; occupancy
+    float best = -FLT_MAX;
+    int best_i = INT_MAX, free_slot = INT_MAX, cnt = 0;
+    for (int j = tid; j < nslots; j += 256) {
+        if (occupied[j]) {
+            ++cnt;
+            const float s = scores[j];
+            if (s > best || (s == best && j < best_i)) { best = s; best_i = j; }
+        } else if (j < free_slot) {
+            free_slot = j;
+        }
+    }
+    red_v[tid] = best; red_i[tid] = best_i;
+    __syncthreads();
+    for (int st = 128; st >= 1; st >>= 1) {
+        if (tid < st && before(red_v[tid + st], red_i[tid + st], red_v[tid], red_i[tid])) {
+            red_v[tid] = red_v[tid + st]; red_i[tid] = red_i[tid + st];
+        }
+        __syncthreads();
+    }
+    const float similarity = red_i[0] == INT_MAX ? 0.f : red_v[0];
+    __syncthreads();
+    red_i[tid] = free_slot; red_v[tid] = (float)cnt;
+    __syncthreads();
+    for (int st = 128; st >= 1; st >>= 1) {
+        if (tid < st) { red_i[tid] = min(red_i[tid], red_i[tid + st]); red_v[tid] += red_v[tid + st]; }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        sh_slot = red_i[0] == INT_MAX ? nslots : red_i[0];
+        sh_count = (int)red_v[0];
+        sim_out[0] = similarity;
+    }
+    __syncthreads();
+    const int slot = sh_slot;
+    const bool accept = similarity < threshold && slot < max_slots;
+    if (!accept) {
+        if (tid == 0) { result[0] = 0; result[1] = -1; result[2] = -1; result[3] = sh_count; }
+        return;
+    }
+    // 2. store the sample and its similarities
+    float qq = 0.f;
+    for (int i = tid; i < d; i += 256) {
+        const float v = q[i];
+        db[(size_t)slot * d + i] = v;
+        qq = fmaf(v, v, qq);
+    }
+    __syncthreads();
+    red_v[tid] = qq;
+    __syncthreads();
+    for (int st = 128; st >= 1; st >>= 1) {
+        if (tid < st) red_v[tid] += red_v[tid + st];
+        __syncthreads();
+    }
+    qq = red_v[0];
+    __syncthreads();
+    const int n_after = max(nslots, slot + 1);
+    for (int j = tid; j < n_after; j += 256) {
+        const float s = j == slot ? qq : (occupied[j] ? scores[j] : -1.f);
+        S[(size_t)slot * ld + j] = s;
+        S[(size_t)j * ld + slot] = s;
+    }
+    __syncthreads();
+    if (tid == 0) occupied[slot] = 1;
+    __syncthreads();
+    const int count = sh_count + 1;
+    int evict = -1;
+    if (count > capacity) {
+        // 3. column sums in slot order (coalesced across the columns), minus the self-similarity
+        float bv = -FLT_MAX;
+        int bi = INT_MAX;
+        for (int j = tid; j < n_after; j += 256) {
+            if (!occupied[j]) continue;
+            float acc = 0.f;
+            for (int i = 0; i < n_after; ++i)
+                if (occupied[i]) acc += S[(size_t)i * ld + j];
+            acc -= S[(size_t)j * ld + j];
+            if (acc > bv) { bv = acc; bi = j; }          // ascending j per thread: first maximum kept
+        }
+        red_v[tid] = bv; red_i[tid] = bi;
+        __syncthreads();
+        for (int st = 128; st >= 1; st >>= 1) {
+            if (tid < st && before(red_v[tid + st], red_i[tid + st], red_v[tid], red_i[tid])) {
+                red_v[tid] = red_v[tid + st]; red_i[tid] = red_i[tid + st];
+            }
+            __syncthreads();
+        }
+        evict = red_i[0];
+        __syncthreads();
+        for (int j = tid; j < n_after; j += 256) {          // replay_buffer.py:143-145
+            S[(size_t)evict * ld + j] = -1.f;
+            S[(size_t)j * ld + evict] = -1.f;
+        }
+        if (tid == 0) occupied[evict] = 0;
+    }
+    if (tid == 0) { result[0] = 1; result[1] = slot; result[2] = evict; result[3] = count - (evict >= 0 ? 1 : 0); }
+}
+
 }  // namespace clslam
 
 using namespace clslam;
@@ -125,4 +257,24 @@ extern "C" int clslam_topk_desc(const float* scores, int n, int nq, int k, float
     hipLaunchKernelGGL(topk_sort_kernel, dim3(1, nq), dim3(256), 0, st, (const float*)cand_val, (const int*)cand_idx, chunks * k, k,
                        out_val, out_idx);
     return check_launch("topk_desc");
+}
+
+extern "C" int clslam_l2_normalize_rows(float* x, int n, int d, void* stream) {
+    CLSLAM_REQUIRE(n >= 0 && d >= 1, "l2_normalize_rows: bad sizes");
+    if (n == 0) return CLSLAM_OK;
+    CLSLAM_REQUIRE(x, "l2_normalize_rows: null");
+    hipLaunchKernelGGL(l2_normalize_kernel, dim3(cdiv(n, 4)), dim3(256), 0, (hipStream_t)stream, x, n, d);
+    return check_launch("l2_normalize_rows");
+}
+
+extern "C" int clslam_diversity_commit(float* db, float* sim, int ld, unsigned char* occupied, int nslots, int max_slots, int d,
+                                       int capacity, float threshold, const float* query, const float* scores, int* result,
+                                       float* similarity, void* stream) {
+    CLSLAM_REQUIRE(db && sim && occupied && query && result && similarity, "diversity_commit: null");
+    CLSLAM_REQUIRE(nslots >= 0 && nslots <= max_slots && max_slots <= ld && d >= 1 && capacity >= 1,
+                   "diversity_commit: bad sizes");
+    CLSLAM_REQUIRE(scores || nslots == 0, "diversity_commit: scores missing");
+    hipLaunchKernelGGL(diversity_commit_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, db, sim, ld, occupied, nslots,
+                       max_slots, d, capacity, threshold, query, scores, result, similarity);
+    return check_launch("diversity_commit");
 }

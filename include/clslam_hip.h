@@ -292,6 +292,19 @@ int clslam_ip_scores(const float* db, const float* queries, float* scores, int n
 int clslam_topk_chunks(int n);
 int clslam_topk_desc(const float* scores, int n, int nq, int k, float* cand_val, int* cand_idx, float* out_val,
                      int* out_idx, void* stream);
+/* faiss.normalize_L2 on device rows (loop_closure_detection.py:47, replay_buffer.py:102,215): x_i *= 1/sqrt(<x_i,x_i>),
+ * zero rows untouched. */
+int clslam_l2_normalize_rows(float* x, int n, int d, void* stream);
+/* One candidate of the replay buffer's diversity bookkeeping (slam/replay_buffer.py:104-152, maximize_diversity):
+ * db (max_slots,d) vectors and sim (ld,ld) similarity matrix in SLOT order, occupied[max_slots] flags, `scores`
+ * = clslam_ip_scores(db, query) over the first nslots slots.  Accepts the candidate when its largest similarity to
+ * an occupied slot is < threshold (0 for an empty buffer), writes it to the first free slot (or slot nslots) with
+ * its row/column of sim, and when more than `capacity` slots are occupied evicts argmax_j(sum_i sim[i][j] -
+ * sim[j][j]) (row/column set to -1, slot freed).  result[4] = {accepted, slot written, slot evicted, occupied
+ * count}; similarity[0] = the nearest stored similarity.  One workgroup; no host decision between the steps. */
+int clslam_diversity_commit(float* db, float* sim, int ld, unsigned char* occupied, int nslots, int max_slots, int d,
+                            int capacity, float threshold, const float* query, const float* scores, int* result,
+                            float* similarity, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Image-pyramid ingest: the reference's datasets resize every pyramid level from the

@@ -1,0 +1,151 @@
+"""TEST INFRASTRUCTURE: stand-ins for the third-party packages the REFERENCE's caller modules import and the build
+container lacks, so that config/config_parser.py, slam/slam.py, slam/replay_buffer.py and
+datasets/* import and RUN unchanged on top of the cl-slam_amd packages:
+
+  g2o                      a functional in-memory pose graph (vertices / edges / estimates; optimize() is a no-op)
+  torchvision.transforms   Resize(LANCZOS) / ToTensor / ToPILImage / Compose / Lambda on PIL, functional.adjust_*
+  torchvision.models       placeholder (the reference's own network classes are shadowed by cl-slam_amd's)
+  cv2, wandb, colour_demosaicing, skimage   MagicMock (never called on the driven path)
+
+Only tests import this module."""
+import enum
+import sys
+import types
+from unittest.mock import MagicMock
+
+import numpy as np
+import torch
+
+
+def _g2o() -> types.ModuleType:
+    g = types.ModuleType('g2o')
+
+    class Isometry3d:
+        def __init__(self, m=None):
+            self._m = np.eye(4) if m is None else np.array(m, dtype=np.float64)
+
+        def matrix(self):
+            return self._m
+
+    class VertexSE3:
+        def __init__(self):
+            self._id, self._est, self._fixed = None, Isometry3d(), False
+
+        def set_id(self, i): self._id = i
+        def id(self): return self._id
+        def set_estimate(self, e): self._est = e
+        def estimate(self): return self._est
+        def set_fixed(self, f): self._fixed = f
+
+    class VertexPointXYZ(VertexSE3):
+        pass
+
+    class EdgeSE3:
+        def __init__(self):
+            self.v, self.measurement, self.information = {}, None, None
+
+        def set_vertex(self, i, v): self.v[i] = v
+        def set_measurement(self, m): self.measurement = m
+        def set_information(self, info): self.information = np.asarray(info)
+        def set_robust_kernel(self, k): pass
+        def set_parameter_id(self, a, b): pass
+
+    class SparseOptimizer:
+        def __init__(self):
+            self._vertices, self._edges, self.optimize_calls = {}, [], 0
+
+        def set_algorithm(self, s): pass
+        def add_parameter(self, p): pass
+        def vertices(self): return self._vertices
+        def vertex(self, i): return self._vertices[i]
+        def add_vertex(self, v): self._vertices[v.id()] = v
+        def add_edge(self, e): self._edges.append(e)
+        def initialize_optimization(self): pass
+        def set_verbose(self, v): pass
+
+        def optimize(self, n):
+            self.optimize_calls += 1
+
+    class _Opaque:
+        def __init__(self, *a, **k): pass
+        def set_id(self, i): pass
+
+    g.Isometry3d, g.VertexSE3, g.VertexPointXYZ, g.EdgeSE3, g.EdgeSE3PointXYZ = Isometry3d, VertexSE3, VertexPointXYZ, EdgeSE3, EdgeSE3
+    g.SparseOptimizer = SparseOptimizer
+    for n in ('BlockSolverSE3', 'LinearSolverCholmodSE3', 'OptimizationAlgorithmLevenberg', 'ParameterSE3Offset',
+              'RobustKernelHuber'):
+        setattr(g, n, _Opaque)
+    return g
+
+
+def _torchvision():
+    from PIL import Image
+    tv = types.ModuleType('torchvision')
+    T = types.ModuleType('torchvision.transforms')
+    F = types.ModuleType('torchvision.transforms.functional')
+
+    class InterpolationMode(enum.Enum):
+        LANCZOS = 'lanczos'
+        BILINEAR = 'bilinear'
+
+    class Resize:
+        def __init__(self, size, interpolation=InterpolationMode.BILINEAR):
+            self.size, self.mode = size, interpolation
+
+        def __call__(self, img):
+            h, w = self.size
+            return img.resize((w, h), Image.LANCZOS if self.mode == InterpolationMode.LANCZOS else Image.BILINEAR)
+
+    class ToTensor:
+        def __call__(self, img):
+            if isinstance(img, np.ndarray):           # torchvision: (H,W[,C]) array -> (C,H,W), floats unscaled
+                a = img[:, :, None] if img.ndim == 2 else img
+                return torch.from_numpy(np.ascontiguousarray(a.transpose(2, 0, 1)))
+            a = np.asarray(img, dtype=np.float32) / 255.0
+            return torch.from_numpy(np.ascontiguousarray(a.transpose(2, 0, 1)))
+
+    class ToPILImage:
+        def __call__(self, t):
+            return Image.fromarray((t.clamp(0, 1) * 255).round().byte().permute(1, 2, 0).numpy())
+
+    class Compose:
+        def __init__(self, ts): self.ts = ts
+
+        def __call__(self, x):
+            for t in self.ts:
+                x = t(x)
+            return x
+
+    class Lambda:
+        def __init__(self, fn): self.fn = fn
+        def __call__(self, x): return self.fn(x)
+
+    def _blend(a, b, f):
+        return (f * a + (1 - f) * b).clamp(0, 1)
+
+    def _gray(x):
+        return (0.299 * x[..., 0:1, :, :] + 0.587 * x[..., 1:2, :, :] + 0.114 * x[..., 2:3, :, :])
+
+    # tensor versions (the replay buffer jitters tensors, replay_buffer.py:281-282); plain blends, hue left alone
+    F.adjust_brightness = lambda x, f: _blend(x, torch.zeros_like(x), f)
+    F.adjust_contrast = lambda x, f: _blend(x, _gray(x).mean(dim=(-3, -2, -1), keepdim=True), f)
+    F.adjust_saturation = lambda x, f: _blend(x, _gray(x), f)
+    F.adjust_hue = lambda x, f: x
+    T.InterpolationMode, T.Resize, T.ToTensor, T.ToPILImage, T.Compose, T.Lambda = (InterpolationMode, Resize, ToTensor,
+                                                                                      ToPILImage, Compose, Lambda)
+    T.Normalize = MagicMock()
+    T.functional = F
+    models = MagicMock()
+    tv.transforms, tv.models = T, models
+    return {'torchvision': tv, 'torchvision.transforms': T, 'torchvision.transforms.functional': F,
+            'torchvision.models': models, 'torchvision.models.feature_extraction': MagicMock(),
+            'torchvision.models.resnet': MagicMock()}
+
+
+def install() -> None:
+    for name in ('cv2', 'wandb', 'colour_demosaicing', 'skimage', 'skimage.transform'):
+        sys.modules[name] = MagicMock()
+    sys.modules['g2o'] = _g2o()
+    sys.modules.update(_torchvision())
+    import matplotlib
+    matplotlib.use('Agg')

@@ -90,6 +90,64 @@ def test_api_corners_match_oracle(backend):
 
 
 @pytest.mark.parametrize('backend', BACKENDS)
+def test_mini_slam_loop(backend, tmp_path, monkeypatch):
+    """GPU twin of tests/test_reference_callers.py (the reference checkout does not travel to the GPU box): the
+    per-frame sequence of slam/slam.py:137-243 on the product packages alone -- encoder descriptor -> replay buffer
+    bookkeeping through the `faiss`-named module (the calls of replay_buffer.py:95-160) and through DiversityBuffer,
+    adapt() on online + replayed samples, LoopClosureDetection.add/search, predict_pose on a detected loop."""
+    dev = use_backend(backend)
+    import faiss
+    from clslam_hip.diversity import DiversityBuffer
+    from loop_closure_detection import Config as LcdConfig
+    from loop_closure_detection import LoopClosureDetection
+    from test_lcd_encoder import _weights
+    torch.save(_weights()[1], tmp_path / 'mbv3.pth')
+    monkeypatch.setenv('CLSLAM_MOBILENETV3_WEIGHTS', str(tmp_path / 'mbv3.pth'))
+    B, cap, thr = 3, 2, 0.9999
+    p = make_predictor(H, W, B, log_path=str(tmp_path))
+    lcd = LoopClosureDetection(LcdConfig(tmp_path / 'x.yaml', 0.9, 2, 1))
+    index = faiss.IndexIDMap(faiss.index_factory(512, 'Flat', faiss.METRIC_INNER_PRODUCT))
+    div = DiversityBuffer(512, cap, thr, dev)
+    frames = [synth.make_batch(1, H, W, seed=40 + (i % 4)) for i in range(6)]     # the camera returns after 4 frames
+    stored = {}
+    closures = []
+    for step, online in enumerate(frames, start=1):
+        p._set_eval()
+        feat = p.models['depth_encoder'](online['rgb', 0, 0].to(p.device))[4].detach().mean(-1).mean(-1)   # slam.py:143-147
+        f_np = feat.cpu().numpy().copy()
+        faiss.normalize_L2(f_np)
+        sim = 0 if index.ntotal == 0 else index.search(f_np, 1)[0][0][0]
+        added, removed, sim_dev = div.add(feat, step)                            # device-resident twin of the same decision
+        assert abs(float(sim) - sim_dev) < 1e-5
+        assert added == bool(sim < thr)
+        if sim < thr:
+            index.add_with_ids(f_np, np.array([step]))
+            stored[step] = online
+            if removed is not None:
+                index.remove_ids(np.array([removed]))
+                del stored[removed]
+        assert sorted(faiss.vector_to_array(index.id_map).tolist()) == sorted(div.ids.tolist()) == sorted(stored)
+        replay_ids = [i for i in stored if i != step][:B - 1]
+        if len(replay_ids) == B - 1:
+            training = online
+            for i in replay_ids:
+                training = _cat_dict(training, stored[i])
+            outputs, losses = p.adapt(online, {k: v.clone() for k, v in training.items()}, steps=1)
+        else:
+            outputs, losses = p.adapt(online, None)
+        assert torch.isfinite(losses['loss']).all() and outputs['cam_T_cam', 0, 1].shape[1:] == (4, 4)
+        image = online['rgb', 1, 0]
+        lcd.add(step, image.squeeze())                                           # slam.py:219
+        ids, dist = lcd.search(step)                                             # slam.py:222
+        for i, d in zip(ids, dist):
+            T, cov = p.predict_pose(image[0], frames[i - 1]['rgb', 1, 0][0], as_numpy=True)   # slam.py:224-229
+            assert T.shape == (4, 4) and np.isfinite(T).all() and d > 0.9
+            closures.append((step, i))
+    assert closures == [(5, 1), (6, 2)], closures                                # identical frames, id gap > 2
+    assert p.engine.adam_step_count >= 2
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
 def test_nan_loss_aborts_without_update(backend):
     """dpp.py:1115-1118: a NaN loss raises RuntimeError('NaN loss') and the optimizer step does not
     happen.  The product checks once per step, after the (device-guarded) Adam launch: weights,
