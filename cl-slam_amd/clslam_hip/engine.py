@@ -103,6 +103,8 @@ class Engine:
             raise ValueError('height and width must be multiples of 32 (five stride-2 stages)')
         if not reference_quirks:
             raise NotImplementedError('only the reference smoothness behaviour (SURVEY.md 0.3) is implemented')
+        if min_depth is None and max_depth is not None:
+            raise ValueError('min_depth is None')        # disp_to_depth, utils.py:134-135
         self.H, self.W, self.device = height, width, device
         self.min_depth, self.max_depth = min_depth, max_depth
         self.smooth_scale = float(disparity_smoothness)
@@ -945,7 +947,11 @@ class Engine:
         self._conv_workspace()
         self.wait_training()
         a, b = self._img(image_0.to(self.device)), self._img(image_1.to(self.device))
-        n = a.shape[0]
+        n = a.shape[0] if a.dim() == 4 else -1
+        # the stem kernel takes H, W from its input but writes buffers planned for the engine's resolution
+        for name, t in (('image_0', a), ('image_1', b)):
+            if tuple(t.shape) != (n, 3, self.H, self.W):
+                raise ClslamError(f'predict_pose: {name} must be (N, 3, {self.H}, {self.W}) with equal N, got {tuple(t.shape)}')
         key = ('pose', n)
         st = self._ws.get(key)
         if st is None:

@@ -479,19 +479,20 @@ class DepthPosePrediction:
         self._mode = 'adapt'
 
     # ============================================================
-    def _sample_weights(self, B: int, loss_sample_weights: Optional[Tensor]):
+    def _sample_weights(self, B: int, loss_sample_weights: Optional[Tensor], local: bool = False):
         """dpp.py:1031-1032 and the broadcasting of a (batch_size,) weight vector against the actual
-        batch (equal sizes, or an actual batch of 1 which sees the SUM of the weights)."""
+        batch (equal sizes, or an actual batch of 1 which sees the SUM of the weights).  local: a forward-only
+        call in data-parallel mode sees its own batch like a single process would (no shard semantics)."""
         if loss_sample_weights is None:      # the default vectors are constants: built once per batch size
-            key = (B, None if self._dp is None else (self._dp['global_batch'], self._dp['offset']))
+            key = (B, None if (self._dp is None or local) else (self._dp['global_batch'], self._dp['offset']))
             hit = self._default_weights.get(key)
             if hit is None:
-                hit = self._default_weights[key] = self._build_sample_weights(B, None)
+                hit = self._default_weights[key] = self._build_sample_weights(B, None, local)
             return hit
-        return self._build_sample_weights(B, loss_sample_weights)
+        return self._build_sample_weights(B, loss_sample_weights, local)
 
-    def _build_sample_weights(self, B: int, loss_sample_weights: Optional[Tensor]):
-        if self._dp is not None:
+    def _build_sample_weights(self, B: int, loss_sample_weights: Optional[Tensor], local: bool = False):
+        if self._dp is not None and not local:
             gb = self._dp['global_batch']
             w = torch.full((gb,), 1.0 / gb, device=self.device) if loss_sample_weights is None else loss_sample_weights
             local = w[self._dp['offset']:self._dp['offset'] + B].contiguous()
@@ -500,6 +501,8 @@ class DepthPosePrediction:
             loss_sample_weights = torch.ones(self.batch_size, device=self.device) / self.batch_size
         if loss_sample_weights.numel() == B:
             w = loss_sample_weights.to(self.device, torch.float32).contiguous()
+        elif loss_sample_weights.numel() == 1:     # (B,) * (1,) broadcasts: every sample gets the single weight
+            w = loss_sample_weights.to(self.device, torch.float32).reshape(1).repeat(B)
         elif B == 1:
             w = loss_sample_weights.to(self.device, torch.float32).sum().reshape(1)
         else:
@@ -514,7 +517,7 @@ class DepthPosePrediction:
             for key, val in inputs.items():  # mutates the caller's dict, like dpp.py:916-917
                 inputs[key] = val.to(self.device)
         B = inputs['rgb_aug', 0, 0].shape[0]
-        sample_w, smooth_w = self._sample_weights(B, loss_sample_weights)
+        sample_w, smooth_w = self._sample_weights(B, loss_sample_weights, local=not train)
         if graphed:
             outputs, losses = self.engine.train_step_graphed(inputs, sample_w=sample_w, smooth_w=smooth_w,
                                                              noise=self._injected_noise, copy_inputs=copy_inputs,
@@ -522,7 +525,9 @@ class DepthPosePrediction:
         else:
             outputs, losses = self.engine.forward(inputs, train=train, sample_w=sample_w, smooth_w=smooth_w,
                                                   noise=self._injected_noise, reuse_frozen=reuse_frozen)
-        if self._dp is not None:
+        if self._dp is not None and train:
+            # only training steps are collective: predict() / adapt(online, None) on one rank (slam.py:178 on the
+            # rank that holds the online frame) must not pair up with another rank's gradient exchange
             self._dp['dist'].all_reduce(losses, group=self._dp['group'])
         loss_dict = self.engine.losses_dict(losses)
         if not train:

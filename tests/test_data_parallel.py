@@ -35,6 +35,13 @@ def _worker(rank, world, port, counts, out_dir):
     out, losses = p.adapt(None, batch, steps=2)      # second step: frozen-feature reuse under data parallelism
     everything = p.gather_outputs(out)               # uneven shards (2 + 1)
     in_sync = p.replicas_in_sync()
+    # forward-only calls are local (slam.py:178 / predict() on the rank that holds the online frame): no
+    # collective, single-process weights.  Only rank 0 calls; a hidden all_reduce would hang or mis-pair here.
+    solo = None
+    if rank == 0:
+        p.set_tie_break_noise({s: v[:1] for s, v in noise.items()})
+        _, solo_l = p.adapt({k: v[:1].clone() for k, v in full.items()}, None)
+        solo = {k: v.clone() for k, v in solo_l.items()}
     if rank == 1:                                    # a single flipped mantissa bit on one rank must be noticed
         p.engine.w.view(torch.int32)[12345] ^= 1
     diverged_seen = not p.replicas_in_sync()
@@ -42,7 +49,7 @@ def _worker(rank, world, port, counts, out_dir):
         p.engine.w.view(torch.int32)[12345] ^= 1
     torch.save({'in_sync': in_sync, 'diverged_seen': diverged_seen, 'full_depth': everything['depth', 0].clone(), 'full_T': everything['cam_T_cam', 0, -1].clone(),
                 'g': p.engine.g.clone(), 'w': p.engine.w.clone(), 'loss': {k: v.clone() for k, v in losses.items()},
-                'T': out['cam_T_cam', 0, 1].clone()}, Path(out_dir) / f'rank{rank}.pt')
+                'T': out['cam_T_cam', 0, 1].clone(), 'solo': solo}, Path(out_dir) / f'rank{rank}.pt')
     dist.destroy_process_group()
 
 
@@ -72,6 +79,11 @@ def test_two_ranks_equal_single_rank(tmp_path):
     for k, v in losses.items():
         assert abs(float(r0['loss'][k]) - float(v)) <= 2e-5 * max(abs(float(v)), 1e-3), k   # losses of the 2nd step
     assert torch.allclose(r0['T'], out['cam_T_cam', 0, 1][:2], atol=1e-6)
+    # rank 0's forward-only call on the online sample == a single process doing the same (after the same 2 steps)
+    p.set_tie_break_noise({s: v[:1] for s, v in synth.make_noise(B, H, W, seed=8).items()})
+    _, solo = p.adapt({k: v[:1].clone() for k, v in full.items()}, None)
+    for k, v in solo.items():
+        assert abs(float(r0['solo'][k]) - float(v)) <= 1e-4 * max(abs(float(v)), 1e-3), k
     # the explicit all-gather helper: the single-process full-batch dict, identical on both ranks
     for r in (r0, r1):
         assert r['in_sync'] and r['diverged_seen']

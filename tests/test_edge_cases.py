@@ -63,3 +63,34 @@ def test_predictor_validation_matches_reference_constructor(backend):
         p.adapt(None, bad, steps=1)
     with pytest.raises(ClslamError):
         p.predict({k: (v[..., :96] if v.dim() == 4 else v) for k, v in synth.make_batch(1, 64, 128, seed=0).items()})   # wrong width
+    # predict_pose validates like run_encoder/forward (the stem kernel takes H, W from its input)
+    good = synth.make_batch(1, 64, 128, seed=0)['rgb', 0, 0]
+    with pytest.raises(ClslamError, match='predict_pose'):
+        p.predict_pose(good[0], good[0, :, :, :96])
+    with pytest.raises(ClslamError, match='predict_pose'):
+        p.predict_pose(good, torch.cat([good, good]))
+    T, cov = p.predict_pose(good[0], good[0])
+    assert T.shape == (4, 4)
+    # disp_to_depth (utils.py:134-135): max_depth without min_depth is refused
+    with pytest.raises(ValueError, match='min_depth is None'):
+        make_predictor(64, 128, 1, min_depth=None, max_depth=80.0)
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_single_weight_broadcasts_over_the_batch(backend):
+    """a configured batch_size of 1 with a larger actual batch: the reference's (1,) weight vector broadcasts
+    (dpp.py:1031-1032, :1073) -- every sample is weighted 1, the loss is the SUM over samples"""
+    use_backend(backend)
+    from clslam_hip import synth
+    from predictor_util import make_predictor
+    p = make_predictor(64, 128, 1)
+    two = synth.make_batch(2, 64, 128, seed=5)
+    noise = synth.make_noise(2, 64, 128, seed=5)
+    p.set_tie_break_noise(noise)
+    _, l2 = p.adapt({k: v.clone() for k, v in two.items()}, None)
+    parts = []
+    for i in range(2):
+        p.set_tie_break_noise({s: v[i:i + 1] for s, v in noise.items()})
+        _, li = p.adapt({k: v[i:i + 1].clone() for k, v in two.items()}, None)
+        parts.append(float(li['reprojection_loss/scale_0']))
+    assert abs(float(l2['reprojection_loss/scale_0']) - sum(parts)) < 1e-5 * sum(parts)
