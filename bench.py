@@ -236,6 +236,11 @@ def main():
                  4: 'conv_igemm_kernel<128, 16, 16, 16, 4>', 5: 'conv_igemm_kernel<64, 32, 16, 16, 2>',
                  6: 'conv_igemm_kernel<128, 16, 32, 16, 4>'}
         names.update({k: f'conv3x3_patch_kernel<{v}, false>' for k, v in patch.items()})
+        # stream-K kernels (template arguments TH, TW, RUN, S, BN, NWM, NWN; the stride-2 layers use S = 2)
+        names.update({30: 'conv3x3_sk_kernel<8, 16, false, 1, 64, 4, 2>', 31: 'conv3x3_sk_kernel<4, 16, false, 1, 64, 4, 2>',
+                      32: 'conv3x3_sk_kernel<8, 16, true, 1, 64, 4, 2>', 33: 'conv3x3_sk_kernel<4, 16, true, 1, 64, 4, 2>',
+                      34: 'conv3x3_sk_kernel<8, 16, false, 1, 32, 4, 1>', 35: 'conv3x3_sk_kernel<4, 16, false, 1, 32, 2, 2>',
+                      36: 'conv3x3_sk_kernel<4, 16, true, 1, 32, 2, 2>', 37: 'conv3x3_sk_kernel<8, 16, true, 1, 32, 4, 1>'})
         (kind, cfg), (fl, tt, cnt) = max(agg.items(), key=lambda kv: kv[1][1])
         all_fl = sum(a[0] for a in agg.values())
         all_t = sum(a[1] for a in agg.values())

@@ -227,7 +227,8 @@ static int launch_conv(ConvK k, hipStream_t stream) {
 
 }  // namespace clslam
 
-namespace clslam { int conv3x3_patch_dispatch(const clslam_conv_desc* d, int cfg, hipStream_t stream); }
+namespace clslam { int conv3x3_patch_dispatch(const clslam_conv_desc* d, int cfg, hipStream_t stream);
+                   int conv3x3_sk_dispatch(const clslam_conv_desc* d, int cfg, hipStream_t stream); }
 
 using namespace clslam;
 
@@ -249,6 +250,21 @@ extern "C" int clslam_conv2d_pick_config(const clslam_conv_desc* d) {
     // B=5 @192x640): 128 px x 16 ch tiles reach 80-104 TFLOP/s on the >= 48x160 layers, 64 px x 16 ch
     // tiles 65-95 TFLOP/s on the smaller ones, 64-px row-major runs 46-70 TFLOP/s on the 6x20 layers
     // (a 4x16 rectangle wastes half its lanes there); all beat every conv_igemm tiling (26-67).
+    // Deep, small-M layers (the 6x20 / 12x40 stages, 256-512 channels): the persistent stream-K kernel (conv_sk.hip).
+    // Measured on MI355X, B=5 / 2B=10 (profiles/r02_conv_microbench.txt): layer4 51 -> 67, layer4 (pose) 70 -> 85,
+    // layer3 (pose) 80 -> 87, upconv_4_0 36 -> 50, pose decoder 46 -> 55, upconv_4_1 79 -> 86, layer4.0 (stride 2)
+    // 32 -> 38 TFLOP/s.  On the short-K layers (64-128 channels) every workgroup starts and ends at the same moment and
+    // the synchronized first-load / last-store bursts cost more than the even split gains: those stay on the tiled kernel.
+    const bool sk_ok = d->workspace != nullptr && d->ksize == 3 && d->ch_out >= 64 && !getenv("CLSLAM_NO_STREAMK") &&
+                       d->config != -2;          // config -2: the tiled kernels only (fallback of clslam_conv2d below)
+    static const int sk_all = getenv("CLSLAM_SK_ALL") ? atoi(getenv("CLSLAM_SK_ALL")) : 0;   // experiment knob
+    if (sk_ok && sk_all && Cin >= sk_all) return d->stride == 2 ? (d->out_w <= 44 ? 31 : 30) : (d->out_w <= 44 ? 32 : 30);
+    if (sk_ok && d->stride == 1 && d->out_h == d->in_h + 2 * d->pad - 2 && d->out_w == d->in_w + 2 * d->pad - 2) {
+        if (d->out_w <= 24 && Cin >= 256) return d->ch_out >= 512 ? 32 : 33;
+        if (d->out_w <= 44 && (Cin >= 512 || (Cin >= 256 && M >= 4000))) return 32;
+        if (d->out_w <= 84 && d->out_w > 44 && Cin >= 256) return 30;
+    }
+    if (sk_ok && d->stride == 2 && d->out_w <= 24 && Cin >= 256) return 30;
     if (d->ksize == 3 && d->stride == 1 && d->out_h == d->in_h + 2 * d->pad - 2 && d->out_w == d->in_w + 2 * d->pad - 2) {
         if (d->out_w <= 24) return 22;                         // narrow images: run tiles
         // (config 26, 4x8 px x 32 ch tiles without overhang on 12x40, measured 67 vs 69 TFLOP/s for config 21: not picked)
@@ -294,6 +310,15 @@ extern "C" int clslam_conv2d(const clslam_conv_desc* d, void* stream_) {
     int cfg = d->config;
     const bool bk32 = (Cin % 32 == 0) && (d->ch_b == 0 || d->ch_a % 32 == 0);
     if (cfg < 0) cfg = clslam_conv2d_pick_config(d);
+    if (cfg >= 30) {
+        const int rc = conv3x3_sk_dispatch(d, cfg, stream);
+        if (rc == CLSLAM_OK || d->config >= 0) return rc;
+        // an automatically picked stream-K configuration that does not fit this geometry (run tiles on a wide
+        // image, scratch too small): the tiled kernel serves it
+        clslam_conv_desc tiled = *d;
+        tiled.config = -2;
+        cfg = clslam_conv2d_pick_config(&tiled);
+    }
     if (cfg >= 10) return conv3x3_patch_dispatch(d, cfg, stream);
     const bool need32 = (cfg <= 3 || cfg == 6);
     if (need32 && !bk32) { set_error("conv2d: config %d needs channel multiples of 32", cfg); return CLSLAM_ERR_INVALID; }

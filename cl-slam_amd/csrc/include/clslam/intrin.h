@@ -57,6 +57,94 @@ __device__ __forceinline__ void coherent_store_u32(unsigned* p, unsigned v) { __
 __device__ __forceinline__ unsigned coherent_inc(unsigned* p) { return __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void stores_complete() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
+__device__ __forceinline__ unsigned coherent_load_u32(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void spin_pause() { __builtin_amdgcn_s_sleep(8); }
+
+// LDS-DMA (gfx950 global_load_lds_dwordx4): every lane fetches 16 bytes from ITS OWN global address and the wave's
+// 64 x 16 B land at lds_wave_base + lane * 16 -- contiguous, no VGPR staging, no ds_write.  The transfer is
+// asynchronous: it counts in vmcnt and nothing orders an LDS read behind it except the issuing wave's
+// dma_wait_all() followed by a workgroup barrier for the other waves' reads (MI355X_MICROARCH.md, LDS-DMA).
+__device__ __forceinline__ void lds_dma16(const float* gsrc, float* lds_wave_base) {
+    // Inline asm on purpose: through __builtin_amdgcn_global_load_lds hipcc (ROCm 7.2) treats every DMA as a write
+    // that may alias the next DMA and every ds_read of the same array, and drains vmcnt(0) between them -- the
+    // transfers of a stage ran one after the other and the double buffering never overlapped.  M0 (destination
+    // base) is compiler-reserved: saved and restored inside the statement (cdna_hip_programming.md, asm recipes).
+    unsigned keep;
+    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) float*)lds_wave_base);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+}
+// An MFMA result read by an INLINE-ASM memory instruction: hipcc's hazard recognizer pads its own instructions with the
+// wait states gfx950 needs between an XDL write and a VMEM read of the same VGPR (up to 19), but does not look inside asm
+// statements -- measured: the last lanes of the last MFMA's first result register reached a store stale.  Call once
+// between the MFMAs and the first coherent_store4 of their accumulators.
+__device__ __forceinline__ void mfma_results_settle() { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }
+// 16-byte agent-scope (write-through / L1-bypassing) accesses for cross-workgroup hand-offs inside one launch
+__device__ __forceinline__ void coherent_store4(float* p, f32x4 v) {
+#ifdef CLSLAM_SCALAR_HANDOFF
+    for (int r = 0; r < 4; ++r) __hip_atomic_store(p + r, v[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    // s_nop 1: a store of more than 8 bytes reads its data VGPRs over the cycles after issue; the next instruction may
+    // not overwrite them for two wait states.  hipcc pads its own stores, not asm ones -- with the accumulators in AGPRs
+    // it re-fills the same four VGPRs (v_accvgpr_read) right behind each store and the last lanes stored the NEXT tile's
+    // first register (found on hardware: 4-wave kernels only, the 8-wave ones store straight from the accumulator VGPRs).
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
+#endif
+}
+// Plain 16-byte store that hipcc does not count: its wait-count pass would otherwise treat the store as pending at the
+// next loop header and drain vmcnt(0) there -- together with the LDS-DMA in flight.  The kernel's own dma_wait_all()
+// one unit later covers it.
+__device__ __forceinline__ void uncounted_store4(float* p, float4 v) {
+    f32x4 q = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(p), "v"(q) : "memory");
+}
+// agent-scope flag store, equally uncounted (a 4-byte store has no data-read hazard)
+__device__ __forceinline__ void uncounted_flag_store(unsigned* p, unsigned v) {
+    asm volatile("global_store_dword %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
+}
+// four slab rows 1 KiB apart, one round trip
+__device__ __forceinline__ void coherent_load4x4(const float* p, f32x4& a, f32x4& b, f32x4& c, f32x4& d) {
+#ifdef CLSLAM_SCALAR_HANDOFF
+    for (int r = 0; r < 4; ++r) {
+        a[r] = __hip_atomic_load(p + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        b[r] = __hip_atomic_load(p + 256 + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        c[r] = __hip_atomic_load(p + 512 + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        d[r] = __hip_atomic_load(p + 768 + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return;
+#endif
+    asm volatile("global_load_dwordx4 %0, %4, off sc0 sc1\n\tglobal_load_dwordx4 %1, %4, off offset:1024 sc0 sc1\n\t"
+                 "global_load_dwordx4 %2, %4, off offset:2048 sc0 sc1\n\tglobal_load_dwordx4 %3, %4, off offset:3072 sc0 sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void coherent_load4x2(const float* p, f32x4& a, f32x4& b) {
+#ifdef CLSLAM_SCALAR_HANDOFF
+    for (int r = 0; r < 4; ++r) {
+        a[r] = __hip_atomic_load(p + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        b[r] = __hip_atomic_load(p + 256 + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return;
+#endif
+    asm volatile("global_load_dwordx4 %0, %2, off sc0 sc1\n\tglobal_load_dwordx4 %1, %2, off offset:1024 sc0 sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(a), "=&v"(b) : "v"(p) : "memory");
+}
+// nothing is scheduled across this point (pins the fragment reads of the next tap ahead of the current tap's MFMAs)
+__device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+// vmcnt(0) THROUGH THE BUILTIN: unlike the asm form hipcc's wait-count pass sees it and knows that none of ITS
+// loads/stores is pending afterwards (otherwise it drains vmcnt -- and with it the LDS-DMA in flight -- at the loop
+// header before re-using a register that a store of the previous iteration read)
+__device__ __forceinline__ void vmem_drain_visible() { __builtin_amdgcn_s_waitcnt(0x0F70); }
+__device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// workgroup barrier WITHOUT the vmcnt(0) hipcc attaches to __syncthreads() while LDS-DMA is in flight: LDS
+// reads/writes of this wave are drained (lgkmcnt), the DMA of the NEXT stage stays in flight across it
+__device__ __forceinline__ void wg_barrier_keep_dma() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 // 1/x to 1 ulp (v_rcp_f32) -- for the SSIM / projection quotients of the loss kernels, where an IEEE
 // division costs ~10 instructions and the last ulp is far below the 1e-4 parity bar
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }

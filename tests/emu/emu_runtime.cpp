@@ -144,6 +144,8 @@ void emu_sync_wave() {
 float* emu_wave_scratch() { return W->wave_scratch.data() + (size_t)(W->fibers[W->cur].tid / 64) * 256; }
 int emu_wave_phase() { return (int)W->wave_phase[W->fibers[W->cur].tid / 64]; }
 
+void emu_yield_os() { std::this_thread::yield(); }
+
 void emu_launch(std::function<void()> body, dim3 grid, dim3 block) {
     const size_t nblocks = (size_t)grid.x * grid.y * grid.z;
     if (nblocks == 0) return;

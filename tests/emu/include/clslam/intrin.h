@@ -9,6 +9,8 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+void emu_yield_os();   // emu_runtime.cpp
+
 namespace clslam {
 
 constexpr int kWave = 64;
@@ -66,6 +68,27 @@ inline float coherent_load(const float* p) { float v; __atomic_load(p, &v, __ATO
 inline void coherent_store_u32(unsigned* p, unsigned v) { __atomic_store_n(p, v, __ATOMIC_SEQ_CST); }
 inline unsigned coherent_inc(unsigned* p) { return __atomic_fetch_add(p, 1u, __ATOMIC_SEQ_CST); }
 inline void stores_complete() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+
+inline unsigned coherent_load_u32(const unsigned* p) { return __atomic_load_n(p, __ATOMIC_SEQ_CST); }
+inline void spin_pause() { ::emu_yield_os(); }   // the producer block runs on another host thread
+// LDS-DMA emulated as an immediate copy: lane l's 16 bytes land at lds_wave_base + l * 16
+inline void lds_dma16(const float* gsrc, float* lds_wave_base) { memcpy(lds_wave_base + lane_id() * 4, gsrc, 16); }
+inline void dma_wait_all() {}
+inline void sched_fence() {}
+inline void uncounted_flag_store(unsigned* p, unsigned v) { __atomic_store_n(p, v, __ATOMIC_SEQ_CST); }
+inline void uncounted_store4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+inline void mfma_results_settle() {}
+inline void vmem_drain_visible() {}
+inline void coherent_store4(float* p, f32x4 v) { memcpy(p, &v, 16); __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+inline void coherent_load4x4(const float* p, f32x4& a, f32x4& b, f32x4& c, f32x4& d) {
+    __atomic_thread_fence(__ATOMIC_SEQ_CST);
+    memcpy(&a, p, 16); memcpy(&b, p + 256, 16); memcpy(&c, p + 512, 16); memcpy(&d, p + 768, 16);
+}
+inline void coherent_load4x2(const float* p, f32x4& a, f32x4& b) {
+    __atomic_thread_fence(__ATOMIC_SEQ_CST);
+    memcpy(&a, p, 16); memcpy(&b, p + 256, 16);
+}
+inline void wg_barrier_keep_dma() { emu_sync_block(); }
 
 inline float wave_shfl_xor(float v, int mask) {
     const int l = lane_id();

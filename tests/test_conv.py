@@ -146,6 +146,68 @@ def test_conv2d_split_k(backend, case, monkeypatch):
     assert int(ws[:65536].view(torch.int32).abs().sum()) == 0
 
 
+# B, H, W, Ca, Cb, Cout, stride, pad_mode, ups, act, resid, config, groups
+STREAMK_CASES = [
+    (2, 12, 20, 32, 0, 64, 1, 0, False, 1, True, 30, 5),       # 8x16 rect tiles, ragged image, 2 chunks/tile cut mid-tile
+    (1, 10, 36, 64, 64, 64, 1, 1, True, 2, False, 30, 7),      # upsample + concat + reflect, 8 chunks
+    (3, 6, 20, 48, 0, 128, 1, 0, False, 1, True, 31, 4),       # 4x16 rect, two channel tiles
+    (1, 24, 40, 64, 0, 48, 1, 0, False, 0, False, 30, 256),    # ragged Cout, more groups than useful
+    (2, 6, 20, 128, 0, 64, 1, 0, False, 1, True, 32, 6),       # run tiles: whole 6x20 image in one 128-px run
+    (2, 12, 40, 64, 0, 128, 1, 0, False, 1, False, 32, 9),     # run tiles across rows (12x40)
+    (1, 6, 20, 256, 0, 64, 1, 0, False, 1, False, 33, 16),     # ONE tile pair shared by 16 groups (B=1 regime)
+    (2, 12, 40, 32, 0, 64, 2, 0, False, 1, False, 30, 3),      # stride 2
+    (1, 9, 21, 32, 0, 64, 2, 0, False, 1, True, 31, 5),        # stride 2, odd sizes
+    (1, 14, 44, 32, 0, 64, 1, 0, False, 0, False, 30, 11),     # dgrad-like padded domain (pad = 2 below)
+    (2, 2, 4, 32, 0, 16, 1, 1, False, 2, False, 33, 3),        # tiny image, reflect
+    # 256-thread groups x 32 channels (several groups per CU)
+    (2, 12, 20, 32, 0, 64, 1, 0, False, 1, True, 34, 5),
+    (1, 10, 36, 64, 64, 96, 1, 1, True, 2, False, 34, 7),
+    (2, 12, 40, 32, 0, 64, 2, 0, False, 1, False, 34, 3),
+    (3, 6, 20, 48, 0, 128, 1, 0, False, 1, True, 35, 13),
+    (1, 9, 21, 32, 0, 64, 2, 0, False, 1, True, 35, 5),
+    (2, 6, 20, 128, 0, 64, 1, 0, False, 1, True, 36, 6),
+    (2, 12, 40, 64, 0, 48, 1, 0, False, 1, False, 37, 9),
+]
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+@pytest.mark.parametrize('case', STREAMK_CASES)
+def test_conv2d_stream_k(backend, case, monkeypatch):
+    """conv_sk.hip: persistent evenly-split implicit GEMM.  Same result as torch for every cut of the unit
+    stream (forced through CLSLAM_SK_GROUPS), bitwise repeatable on the same scratch, hand-off flags back at
+    zero afterwards."""
+    dev = use_backend(backend)
+    B, H, W, Ca, Cb, Cout, stride, pad_mode, ups, act, resid, config, groups = case
+    g = torch.Generator().manual_seed(13)
+    Ha, Wa = (H // 2, W // 2) if ups else (H, W)
+    xa = torch.randn(B, Ha, Wa, Ca, generator=g)
+    xb = torch.randn(B, H, W, Cb, generator=g) if Cb else None
+    w = torch.randn(Cout, 9, Ca + Cb, generator=g) * 0.05
+    scale, shift = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.1
+    pad = 2 if (H, W) == (14, 44) else 1
+    Ho, Wo = (H + 2 * pad - 3) // stride + 1, (W + 2 * pad - 3) // stride + 1
+    res = torch.randn(B, Ho, Wo, Cout, generator=g) if resid else None
+    ref = _ref_conv(xa, w, xb=xb, scale=scale, shift=shift, residual=res, ksize=3, stride=stride, pad=pad, pad_mode=pad_mode,
+                    ups=ups, act=act)
+    t = lambda v: None if v is None else v.to(dev)   # noqa: E731
+    ws = torch.zeros(16 << 20, dtype=torch.uint8, device=dev)
+    monkeypatch.setattr(ops, '_CONV_WORKSPACES', {})
+    outs = []
+    for grp in (groups, groups, 1):
+        monkeypatch.setenv('CLSLAM_SK_GROUPS', str(grp))
+        out = torch.full((B, Ho, Wo, Cout), float('nan'), device=dev)
+        ops.conv2d(t(xa), t(w), out, src_b=t(xb), scale=t(scale), shift=t(shift), residual=t(res), ksize=3, stride=stride,
+                   pad=pad, pad_mode=pad_mode, upsample_a=ups, act=act, config=config, workspace=ws)
+        outs.append(out.cpu())
+    assert rel_err(outs[0], ref) < 2e-5, rel_err(outs[0], ref)
+    assert torch.equal(outs[0], outs[1])
+    assert rel_err(outs[0], outs[2]) < 1e-5
+    assert int(ws[:65536].view(torch.int32).abs().sum()) == 0
+    with pytest.raises(Exception, match='workspace'):
+        ops.conv2d(t(xa), t(w), out, src_b=t(xb), ksize=3, stride=stride, pad=pad, pad_mode=pad_mode, upsample_a=ups,
+                   config=config, workspace=None)
+
+
 @pytest.mark.parametrize('backend', BACKENDS)
 def test_conv_profile_hook_times_every_launch(backend):
     """clslam_conv_profile_begin/end (bench.py's roofline leg): one kernel-exact duration per conv2d launch, in order."""

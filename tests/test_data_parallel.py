@@ -14,10 +14,12 @@ ROOT = Path(__file__).resolve().parents[1]
 H, W, B = 64, 128, 3
 
 
-def _worker(rank, world, port, counts, out_dir):
+def _worker(rank, world, port, counts, out_dir, steps, streamk):
     for p in (ROOT / 'cl-slam_amd', ROOT, ROOT / 'tests'):
         sys.path.insert(0, str(p))
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), CLSLAM_EMU_THREADS='4')
+    if not streamk:
+        os.environ['CLSLAM_NO_STREAMK'] = '1'
     torch.set_num_threads(2)
     import torch.distributed as dist
     from clslam_hip import synth
@@ -32,7 +34,7 @@ def _worker(rank, world, port, counts, out_dir):
     noise = synth.make_noise(B, H, W, seed=8)
     p.set_tie_break_noise({s: v[off:off + counts[rank]] for s, v in noise.items()})
     batch = {k: v[off:off + counts[rank]].clone() for k, v in full.items()}
-    out, losses = p.adapt(None, batch, steps=2)      # second step: frozen-feature reuse under data parallelism
+    out, losses = p.adapt(None, batch, steps=steps)  # second step: frozen-feature reuse under data parallelism
     everything = p.gather_outputs(out)               # uneven shards (2 + 1)
     in_sync = p.replicas_in_sync()
     # forward-only calls are local (slam.py:178 / predict() on the rank that holds the online frame): no
@@ -54,7 +56,14 @@ def _worker(rank, world, port, counts, out_dir):
 
 
 @pytest.mark.timeout(900)
-def test_two_ranks_equal_single_rank(tmp_path):
+@pytest.mark.parametrize('steps,streamk', [(2, False), (1, True)])
+def test_two_ranks_equal_single_rank(tmp_path, monkeypatch, steps, streamk):
+    """(2, False): two optimizer steps with the batch-invariant tiled convs only -- a sample's activations do not depend
+    on the shard it sits in, so the two-rank run equals the single-rank run to summation order even after an update.
+    (1, True): the stream-K convs (conv_sk.hip) cut their reduction where the launch's unit count says, i.e. per shard
+    size: results differ in the last bits between shardings, so only the first step is compared tightly."""
+    if not streamk:
+        monkeypatch.setenv('CLSLAM_NO_STREAMK', '1')
     sys.path.insert(0, str(ROOT / 'tests'))
     from clslam_hip import synth
     from emu_util import use_backend
@@ -63,10 +72,10 @@ def test_two_ranks_equal_single_rank(tmp_path):
     p = make_predictor(H, W, B)
     p.set_tie_break_noise(synth.make_noise(B, H, W, seed=8))
     full = synth.make_batch(B, H, W, seed=4)
-    out, losses = p.adapt(None, {k: v.clone() for k, v in full.items()}, steps=2)
+    out, losses = p.adapt(None, {k: v.clone() for k, v in full.items()}, steps=steps)
     counts = [2, 1]
     port = 29500 + (os.getpid() % 2000)
-    mp.start_processes(_worker, args=(2, port, counts, str(tmp_path)), nprocs=2, join=True, start_method='spawn')
+    mp.start_processes(_worker, args=(2, port, counts, str(tmp_path), steps, streamk), nprocs=2, join=True, start_method='spawn')
     r0 = torch.load(tmp_path / 'rank0.pt')
     r1 = torch.load(tmp_path / 'rank1.pt')
     # identical all-reduced gradients and weights on both ranks
@@ -74,16 +83,21 @@ def test_two_ranks_equal_single_rank(tmp_path):
     # equal to the single-rank run up to summation order
     g = p.engine.g
     # (second step: the weights already differ by the summation order of step 1, so does this gradient)
-    assert float((r0['g'] - g).abs().max() / g.abs().max()) < 1e-4
-    assert float((r0['w'] - p.engine.w).abs().max()) < 0.3e-4          # well below one lr-sized flip
+    # (stream-K: last-bit differences of the forward move a bilinear / min kink for a pixel or two -- DESIGN.md section 2)
+    assert float((r0['g'] - g).abs().max() / g.abs().max()) < (1e-3 if streamk else 1e-4)
+    dw = (r0['w'] - p.engine.w).abs()
+    if streamk:      # Adam's first update is lr * sign(g): a near-zero gradient entry may land on the other side (2 lr)
+        assert float(dw.max()) < 2.5e-4 and float((dw > 0.3e-4).float().mean()) < 2e-3
+    else:
+        assert float(dw.max()) < 0.3e-4          # well below one lr-sized flip
     for k, v in losses.items():
-        assert abs(float(r0['loss'][k]) - float(v)) <= 2e-5 * max(abs(float(v)), 1e-3), k   # losses of the 2nd step
+        assert abs(float(r0['loss'][k]) - float(v)) <= 2e-5 * max(abs(float(v)), 1e-3), k   # losses of the last step
     assert torch.allclose(r0['T'], out['cam_T_cam', 0, 1][:2], atol=1e-6)
     # rank 0's forward-only call on the online sample == a single process doing the same (after the same 2 steps)
     p.set_tie_break_noise({s: v[:1] for s, v in synth.make_noise(B, H, W, seed=8).items()})
     _, solo = p.adapt({k: v[:1].clone() for k, v in full.items()}, None)
     for k, v in solo.items():
-        assert abs(float(r0['solo'][k]) - float(v)) <= 1e-4 * max(abs(float(v)), 1e-3), k
+        assert abs(float(r0['solo'][k]) - float(v)) <= (1e-3 if streamk else 1e-4) * max(abs(float(v)), 1e-3), k
     # the explicit all-gather helper: the single-process full-batch dict, identical on both ranks
     for r in (r0, r1):
         assert r['in_sync'] and r['diverged_seen']

@@ -111,7 +111,8 @@ def test_mini_slam_loop(backend, tmp_path, monkeypatch):
     frames = [synth.make_batch(1, H, W, seed=40 + (i % 4)) for i in range(6)]     # the camera returns after 4 frames
     stored = {}
     closures = []
-    for step, online in enumerate(frames, start=1):
+    for step, frame in enumerate(frames, start=1):
+        online = {k: v.clone() for k, v in frame.items()}      # adapt() moves the caller's dict to the device in place
         p._set_eval()
         feat = p.models['depth_encoder'](online['rgb', 0, 0].to(p.device))[4].detach().mean(-1).mean(-1)   # slam.py:143-147
         f_np = feat.cpu().numpy().copy()
@@ -122,7 +123,7 @@ def test_mini_slam_loop(backend, tmp_path, monkeypatch):
         assert added == bool(sim < thr)
         if sim < thr:
             index.add_with_ids(f_np, np.array([step]))
-            stored[step] = online
+            stored[step] = {k: v.clone() for k, v in online.items()}   # the buffer re-loads samples from disk: host copies
             if removed is not None:
                 index.remove_ids(np.array([removed]))
                 del stored[removed]

@@ -52,6 +52,9 @@ def timeit(fn, iters=20):
     return e0.elapsed_time(e1) / iters * 1e-3
 
 
+_sel = __import__('os').environ.get('BENCH_LAYERS')
+if _sel:
+    LAYERS = [LAYERS[int(i)] for i in _sel.split(',')]
 for name, bm, Hi, Wi, Ca, Cb, Cout, k, stride, refl, ups in LAYERS:
     Bn = B * bm
     Ha, Wa = (Hi // 2, Wi // 2) if ups else (Hi, Wi)
@@ -64,11 +67,19 @@ for name, bm, Hi, Wi, Ca, Cb, Cout, k, stride, refl, ups in LAYERS:
     line = f'{name:32s} M={Bn*Ho*Wo:7d} {flops/1e9:7.2f} GF |'
     cfgs = [-1] + ([int(c) for c in sys.argv[2].split(',')] if len(sys.argv) > 2 else [])
     wsk = torch.zeros(32 << 20, dtype=torch.uint8, device=dev)
+    ref_out = None
     for cfg in cfgs:
         try:
+            ws_arg = wsk if cfg >= 30 else None       # stream-K configs need the zero-filled scratch
             t = timeit(lambda: ops.conv2d(xa, w, out, src_b=xb, ksize=k, stride=stride, pad_mode=refl, upsample_a=bool(ups),
-                                          act=1, config=cfg))
+                                          act=1, config=cfg, workspace=ws_arg))
             line += f' c{cfg}:{flops/t/1e12:6.1f}'
+            if cfg == -1:
+                ref_out = out.clone()
+            elif ref_out is not None:
+                err = float((out - ref_out).abs().max() / ref_out.abs().max())
+                if not err < 1e-5:
+                    line += f'(ERR {err:.1e})'
             if cfg == -1 and SPLITK:
                 t = timeit(lambda: ops.conv2d(xa, w, out, src_b=xb, ksize=k, stride=stride, pad_mode=refl, upsample_a=bool(ups),
                                               act=1, config=cfg, workspace=wsk))
