@@ -111,6 +111,8 @@ def main():
     ap.add_argument('--random-images', action='store_true', help='uniform-random image content instead of the smooth synthetic '
                     'frames (SURVEY.md 8d: the photometric min / mask then flips per pixel -- worst case for the loss stage)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--readback', action='store_true', help='also read the pose and the loss scalars back to the host inside '
+                    'the timed region of `value` (slam.py:182-192); always part of also.end_to_end')
     ap.add_argument('--no-also', action='store_true', help='skip the extra adapt(steps=5) timing (profiling runs)')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo lets two '
                     'ranks share one GPU for a functional check of the sharded path)')
@@ -155,12 +157,22 @@ def main():
         for k in list(full):
             if k[0] in ('rgb', 'rgb_aug'):
                 full[k] = torch.rand(full[k].shape, generator=g)
-    batch = {k: v[offset:offset + Bl].to(dev) for k, v in full.items()}
+    shard = {k: v[offset:offset + Bl].contiguous() for k, v in full.items()}
+    batch = {k: v.to(dev) for k, v in shard.items()}
 
     S = args.adapt_steps
 
+    def consume(outputs, losses):
+        """what slam/slam.py:182-192 reads back after every adapt(): the online sample's pose and the loss scalars"""
+        T = outputs['cam_T_cam', 0, 1][0, :].squeeze().cpu().detach().numpy()
+        vals = {k: float(v.squeeze().cpu().detach().numpy()) for k, v in losses.items()}
+        return T, vals
+
     def step():
-        return p.adapt(None, batch, steps=S)
+        out = p.adapt(None, batch, steps=S)
+        if args.readback:
+            consume(*out)
+        return out
 
     def sync():
         if N > 1:
@@ -181,6 +193,32 @@ def main():
         dt = float(t.item())
     ms = dt / args.steps * 1e3
     value = (args.steps / dt) * (B / FRAME_TRIPLETS)
+
+    # ---- SURVEY.md 8(d)'s end-to-end frame: pinned host batch -> adapt() (H2D inside) -> pose + losses on the host -------
+    e2e = None
+    if rank == 0 and N == 1 and not args.no_also:
+        host = {k: v.pin_memory() for k, v in shard.items()}
+
+        def frame():
+            out = p.adapt(None, dict(host), steps=S)     # a fresh dict per frame: adapt() moves its entries in place
+            return consume(*out)
+        for _ in range(3):
+            frame()
+        groups = []
+        for _ in range(3):
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                frame()
+            sync()
+            groups.append((time.perf_counter() - t0) / 10 * 1e3)
+        ms_e2e = sorted(groups)[1]
+        up = [k for k in p.UPLOAD_FIRST + p.UPLOAD_REST if k in host]
+        e2e = {'ms_per_frame': round(ms_e2e, 3), 'frames_per_s': round(1e3 / ms_e2e, 2),
+               'h2d_mbytes_per_frame': round(sum(host[k].numel() * host[k].element_size() for k in up) / 1e6, 2),
+               'h2d_tensors': len(up), 'of_tensors_in_sample_dict': len(host),
+               'includes': 'H2D of the 13 tensors the path reads from pinned host memory (copy stream, network inputs first), '
+                           'adapt(), D2H of cam_T_cam[0] and the loss scalars (slam.py:182-192)'}
 
     also = None
     if N == 1 and S == 1 and not args.no_also:
@@ -274,6 +312,8 @@ def main():
         }
         if also is not None:
             line['also'] = also
+        if e2e is not None:
+            line.setdefault('also', {})['end_to_end'] = e2e
         print(json.dumps(line), flush=True)
     if N > 1:
         dist.destroy_process_group()

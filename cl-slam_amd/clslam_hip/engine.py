@@ -144,6 +144,8 @@ class Engine:
         self._tail_open = False       # backward() left its reduction on tail_stream; adam() closes it
         self._capturing = False
         self.depth_first = os.environ.get('CLSLAM_DEPTH_FIRST', '1') != '0'
+        self.noise_seed = (int(torch.initial_seed()) * 0x9E3779B97F4A7C15 + 0x7F4A7C15) & 0xFFFFFFFFFFFFFFFF or 1
+        self.noise_draws = 0
         self.use_side_stream = os.environ.get('CLSLAM_SIDE_STREAM', '1') != '0'
         # steps 2..S of adapt(steps=S) keep the frozen encoders' features (see forward)
         self.reuse_frozen_features = os.environ.get('CLSLAM_REUSE_FROZEN', '1') != '0'
@@ -423,7 +425,7 @@ class Engine:
     def forward(self, inputs: Dict[Any, torch.Tensor], *, train: bool, sample_w: torch.Tensor,
                 smooth_w: Optional[torch.Tensor], noise: Optional[Dict[int, torch.Tensor]] = None,
                 draw_noise: bool = True, keep_noise: bool = False,
-                reuse_frozen: bool = False) -> Tuple[Dict[Any, torch.Tensor], torch.Tensor]:
+                reuse_frozen: bool = False, inputs_ready=None) -> Tuple[Dict[Any, torch.Tensor], torch.Tensor]:
         """One _process_batch (dpp.py:906-923).  `inputs` tensors must already live on the device.
 
         reuse_frozen: the caller guarantees that `inputs` are the tensors of the previous forward of this
@@ -433,6 +435,11 @@ class Engine:
         flops).  Ignored when no valid features are held."""
         H, W = self.H, self.W
         self._conv_workspace()
+        if inputs_ready is not None:
+            # inputs still crossing PCIe on the caller's copy stream: events (rgb_aug[0] there, all rgb_aug there, everything
+            # there).  The depth net only reads rgb_aug[0], the pose net the three rgb_aug frames; the un-augmented
+            # frames are first needed by the identity maps / the loss stage.
+            torch.cuda.current_stream(self.device).wait_event(inputs_ready[0])
         aug = {f: self._img(inputs['rgb_aug', f, 0]) for f in (-1, 0, 1)}
         rgb = {f: self._img(inputs['rgb', f, 0]) for f in (-1, 0, 1)}
         B = aug[0].shape[0]
@@ -472,7 +479,8 @@ class Engine:
                 return True
             if keep_noise:                       # already copied into ws.noise by the graph driver
                 return True
-            if draw_noise:
+            if draw_noise and self._capturing:
+                # a captured step replays fixed kernel arguments: torch's graph-safe generator keeps the draws fresh
                 ws.noise.normal_().mul_(1e-5)  # dpp.py:1055-1056
                 return True
             return False
@@ -484,6 +492,8 @@ class Engine:
         if wg is not None:
             # the wgrad stream idles during the forward: the input-only work runs there, off the critical path
             wg.wait_stream(torch.cuda.current_stream(self.device))
+            if inputs_ready is not None:
+                wg.wait_event(inputs_ready[2])
             with torch.cuda.stream(wg):
                 have_noise = identity_and_noise()
                 id_ready = torch.cuda.Event()
@@ -494,6 +504,8 @@ class Engine:
 
             def pose_branch():
                 with torch.cuda.stream(side):
+                    if inputs_ready is not None:
+                        side.wait_event(inputs_ready[1])
                     # pose pairs in temporal order (dpp.py:949-955): (-1, 0) and (0, +1), batched as 2B
                     pf4 = ws.pf4 if reuse else self._encoder(self.enc['pose_encoder'], ws.penc, 2 * B,
                                                              [(aug[-1], aug[0], 0, B), (aug[0], aug[1], B, B)])[4]
@@ -525,11 +537,15 @@ class Engine:
             self.wait_training()
             dfeats = ws.dfeats if reuse else self._encoder(self.enc['depth_encoder'], ws.denc, B, [(aug[0], None, 0, B)])
             self._depth_decoder(ws, dfeats)
+            if inputs_ready is not None:
+                torch.cuda.current_stream(self.device).wait_event(inputs_ready[1])
             pf4 = ws.pf4 if reuse else self._encoder(self.enc['pose_encoder'], ws.penc, 2 * B,
                                                      [(aug[-1], aug[0], 0, B), (aug[0], aug[1], B, B)])[4]
             self._pose_decoder(ws, pf4)
         ws.dfeats, ws.pf4 = dfeats, pf4
         # view synthesis + loss ------------------------------------------------------------------
+        if inputs_ready is not None:
+            torch.cuda.current_stream(self.device).wait_event(inputs_ready[2])
         K = self._mat(inputs['camera_matrix', 0])
         Kinv = self._mat(inputs['inv_camera_matrix', 0])
         ops.pose_to_proj(ws.pose, K, ws.T, ws.P)
@@ -540,8 +556,15 @@ class Engine:
             have_noise = identity_and_noise()
         # all four scales in one launch; reprojection maps stay in registers, only the selected frame's
         # SSIM coefficients are kept for the backward
-        ops.photo_automask_pyramid(ws.warped, rgb[0], ws.idmap, ws.noise if have_noise else None, ws.sel,
-                                   ws.coef if train else None, ws.partial, B, H, W)
+        if have_noise or not draw_noise:
+            ops.photo_automask_pyramid(ws.warped, rgb[0], ws.idmap, ws.noise if have_noise else None, ws.sel,
+                                       ws.coef if train else None, ws.partial, B, H, W)
+        else:
+            # dpp.py:1055-1056 draws randn * 1e-5 on the compute device every scale, every step: here inside the kernel
+            # (Philox keyed by torch's seed, one draw offset per forward) -- no noise tensor is written or read
+            self.noise_draws += 1
+            ops.photo_automask_pyramid_rng(ws.warped, rgb[0], ws.idmap, self.noise_seed, self.noise_draws, ws.sel,
+                                           ws.coef if train else None, ws.partial, B, H, W)
         ops.disp_mean_pyramid(ws.disp, ws.means, H, W)
         n_smooth = 0 if smooth_w is None else int(smooth_w.numel())
         if n_smooth and not (n_smooth < (W >> 3) - 1):

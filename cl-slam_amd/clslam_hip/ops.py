@@ -435,6 +435,18 @@ def photo_automask_pyramid(warped, target, idmap, noise, sel, coef_sel, partial,
                         _p(coef_sel), _p(partial), batch, H, W, _stream(warped))
 
 
+def photo_automask_pyramid_rng(warped, target, idmap, seed, offset, sel, coef_sel, partial, batch, H, W):
+    """tie-break noise drawn in the kernel (Philox): seed != 0, offset = draw counter of the step"""
+    _lib.get_lib().call('clslam_photo_automask_pyramid_rng', _p(warped), _p(target), _p(idmap), int(seed), int(offset),
+                        _pa(sel, torch.uint8), _p(coef_sel), _p(partial), batch, H, W, _stream(warped))
+
+
+def tie_break_noise(out, seed, offset):
+    """out (..., 2) fp32: the in-kernel tie-break stream, element e -> out.view(-1, 2)[e]"""
+    _lib.get_lib().call('clslam_tie_break_noise', _p(out), out.numel() // 2, int(seed), int(offset), _stream(out))
+    return out
+
+
 def loss_bwd2_blocks(H, W) -> int:
     return _lib.get_lib().cdll.clslam_loss_bwd2_blocks(H, W)
 

@@ -259,12 +259,15 @@ extern "C" int clslam_conv2d_pick_config(const clslam_conv_desc* d) {
                        d->config != -2;          // config -2: the tiled kernels only (fallback of clslam_conv2d below)
     static const int sk_all = getenv("CLSLAM_SK_ALL") ? atoi(getenv("CLSLAM_SK_ALL")) : 0;   // experiment knob
     if (sk_ok && sk_all && Cin >= sk_all) return d->stride == 2 ? (d->out_w <= 44 ? 31 : 30) : (d->out_w <= 44 ? 32 : 30);
-    if (sk_ok && d->stride == 1 && d->out_h == d->in_h + 2 * d->pad - 2 && d->out_w == d->in_w + 2 * d->pad - 2) {
+    // (a tile shared by more than ~8 workgroups makes its owner gather that many slabs one after the other: with fewer
+    // than 32 tiles of 128 px x 64 ch -- the B = 1 minibatch on the 6x20 layers -- the tiled kernel is the faster one)
+    const bool sk_fill = (long long)d->batch * cdiv(d->out_h * d->out_w, 128) * cdiv(d->ch_out, 64) >= 32;
+    if (sk_ok && sk_fill && d->stride == 1 && d->out_h == d->in_h + 2 * d->pad - 2 && d->out_w == d->in_w + 2 * d->pad - 2) {
         if (d->out_w <= 24 && Cin >= 256) return d->ch_out >= 512 ? 32 : 33;
         if (d->out_w <= 44 && (Cin >= 512 || (Cin >= 256 && M >= 4000))) return 32;
         if (d->out_w <= 84 && d->out_w > 44 && Cin >= 256) return 30;
     }
-    if (sk_ok && d->stride == 2 && d->out_w <= 24 && Cin >= 256) return 30;
+    if (sk_ok && sk_fill && d->stride == 2 && d->out_w <= 24 && Cin >= 256) return 30;
     if (d->ksize == 3 && d->stride == 1 && d->out_h == d->in_h + 2 * d->pad - 2 && d->out_w == d->in_w + 2 * d->pad - 2) {
         if (d->out_w <= 24) return 22;                         // narrow images: run tiles
         // (config 26, 4x8 px x 32 ch tiles without overhang on 12x40, measured 67 vs 69 TFLOP/s for config 21: not picked)

@@ -37,11 +37,51 @@ constexpr int PA_TH = 8, PA_TW = 64, PA_PH = PA_TH + 2, PA_PW = PA_TW + 2;
 // staging) are read from HBM once (x1.29 halo) instead of 9x through L1 per window; the 3x3 statistics
 // then come from LDS.  TRAIN: coef_sel_all != nullptr (a runtime pointer select would push the
 // coefficient arrays to scratch).
+// Tie-break noise of dpp.py:1055-1056 (`identity_reprojection_losses += randn(...) * 1e-5`) drawn inside the kernel:
+// Philox4x32-10 keyed by the caller's seed, counter = (element index, draw offset of the step) -> two N(0,1) samples
+// by Box-Muller.  The reference's generator is torch's global one on the compute device; its stream is not
+// reproducible across devices either, parity runs inject captured tensors instead (set_tie_break_noise).
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1,
+                                              unsigned (&out)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// element e of the draw `offset`: noise for the two identity channels of one pixel
+__device__ __forceinline__ void tie_break_pair(unsigned long long seed, unsigned long long offset, unsigned long long e,
+                                               float& n0, float& n1) {
+    unsigned r[4];
+    philox4x32_10((unsigned)e, (unsigned)(e >> 32), (unsigned)offset, (unsigned)(offset >> 32), (unsigned)seed,
+                  (unsigned)(seed >> 32), r);
+    const float u1 = ((float)(r[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);        // (0, 1)
+    const float u2 = ((float)(r[1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float rad = sqrtf(-2.0f * logf(u1)) * 1e-5f;
+    float sn, cs;
+    sincosf(6.283185307179586f * u2, &sn, &cs);
+    n0 = rad * cs; n1 = rad * sn;
+}
+
+__global__ __launch_bounds__(256) void tie_break_noise_kernel(float* __restrict__ out, size_t npix, unsigned long long seed,
+                                                              unsigned long long offset) {
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= npix) return;
+    float a, b;
+    tie_break_pair(seed, offset, e, a, b);
+    out[2 * e] = a; out[2 * e + 1] = b;
+}
+
 template <bool TRAIN>
 __global__ __launch_bounds__(256) void photo_automask_kernel(const float* __restrict__ warped_all, const float* __restrict__ target,
                                                              const float* __restrict__ idmap, const float* __restrict__ noise_all,
                                                              unsigned char* __restrict__ sel_all, float* __restrict__ coef_sel_all,
-                                                             float* __restrict__ partial_all, int B, int H, int W, int tilesX) {
+                                                             float* __restrict__ partial_all, int B, int H, int W, int tilesX,
+                                                             unsigned long long seed, unsigned long long rng_offset) {
     __shared__ float tl[9][PA_PH * PA_PW];   // planes 0-2: target, 3-5: warped frame 0, 6-8: warped frame 1
     __shared__ float red[4];
     const float C1 = 0.0001f, C2 = 0.0009f;
@@ -121,6 +161,11 @@ __global__ __launch_bounds__(256) void photo_automask_kernel(const float* __rest
         float c0 = idmap[((size_t)0 * B + b) * HW + p];
         float c1 = idmap[((size_t)1 * B + b) * HW + p];
         if (noise) { c0 += noise[((size_t)b * 2 + 0) * HW + p]; c1 += noise[((size_t)b * 2 + 1) * HW + p]; }
+        else if (seed) {
+            float z0, z1;
+            tie_break_pair(seed, rng_offset, ((size_t)sc * B + b) * HW + p, z0, z1);
+            c0 += z0; c1 += z1;
+        }
         float m = c0; int k = 0;
         if (c1 < m) { m = c1; k = 1; }
         if (c2 < m) { m = c2; k = 2; }
@@ -855,20 +900,41 @@ extern "C" int clslam_disp_mean_pyramid(const float* const* disp, float* psum, i
 
 // Fused photometric map + automask over the pyramid: warped (4,2,B,3,H,W), idmap (2,B,H,W), noise (4,B,2,H,W)|NULL ->
 // sel (4,B,H,W), coef_sel (4,B,9,H,W)|NULL (training only), partial (4,B,clslam_automask_blocks).
-extern "C" int clslam_photo_automask_pyramid(const float* warped, const float* target, const float* idmap, const float* noise,
-                                             unsigned char* sel, float* coef_sel, float* partial, int batch, int H, int W,
-                                             void* stream) {
+static int photo_automask_launch(const float* warped, const float* target, const float* idmap, const float* noise,
+                                 unsigned char* sel, float* coef_sel, float* partial, int batch, int H, int W,
+                                 unsigned long long seed, unsigned long long offset, void* stream) {
     CLSLAM_REQUIRE(warped && target && idmap && sel && partial && H >= 2 && W >= 2, "photo_automask_pyramid: bad args");
     if (!batch) return CLSLAM_OK;
     const int nblk = clslam_automask_blocks(H, W);   // = number of 8 x 64 tiles
     const int tilesX = cdiv(W, PA_TW);
     if (coef_sel)
         hipLaunchKernelGGL(photo_automask_kernel<true>, dim3(nblk, batch, 4), dim3(256), 0, (hipStream_t)stream, warped, target,
-                           idmap, noise, sel, coef_sel, partial, batch, H, W, tilesX);
+                           idmap, noise, sel, coef_sel, partial, batch, H, W, tilesX, seed, offset);
     else
         hipLaunchKernelGGL(photo_automask_kernel<false>, dim3(nblk, batch, 4), dim3(256), 0, (hipStream_t)stream, warped, target,
-                           idmap, noise, sel, coef_sel, partial, batch, H, W, tilesX);
+                           idmap, noise, sel, coef_sel, partial, batch, H, W, tilesX, seed, offset);
     return check_launch("photo_automask_pyramid");
+}
+
+extern "C" int clslam_photo_automask_pyramid(const float* warped, const float* target, const float* idmap, const float* noise,
+                                             unsigned char* sel, float* coef_sel, float* partial, int batch, int H, int W,
+                                             void* stream) {
+    return photo_automask_launch(warped, target, idmap, noise, sel, coef_sel, partial, batch, H, W, 0ull, 0ull, stream);
+}
+
+extern "C" int clslam_photo_automask_pyramid_rng(const float* warped, const float* target, const float* idmap,
+                                                 unsigned long long seed, unsigned long long offset, unsigned char* sel,
+                                                 float* coef_sel, float* partial, int batch, int H, int W, void* stream) {
+    CLSLAM_REQUIRE(seed != 0, "photo_automask_pyramid_rng: seed must be non-zero");
+    return photo_automask_launch(warped, target, idmap, nullptr, sel, coef_sel, partial, batch, H, W, seed, offset, stream);
+}
+
+extern "C" int clslam_tie_break_noise(float* out, size_t npix, unsigned long long seed, unsigned long long offset, void* stream) {
+    CLSLAM_REQUIRE(out || npix == 0, "tie_break_noise: null");
+    if (!npix) return CLSLAM_OK;
+    hipLaunchKernelGGL(tie_break_noise_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out, npix,
+                       seed, offset);
+    return check_launch("tie_break_noise");
 }
 
 extern "C" int clslam_loss_bwd2_blocks(int H, int W) { return cdiv(H, LB_TH) * cdiv(W, LB_TW); }

@@ -220,9 +220,13 @@ class DepthPosePrediction:
         self._dp = None
         self._default_weights: Dict[Any, Any] = {}
         self._injected_noise = None
-        self._loss_host = None   # pinned 1-float staging buffer + event for the per-step NaN check
+        self._loss_host = None   # pinned 18-float staging buffer + event: the step's loss scalars (NaN check, return value)
         self._loss_event = None
         self._mode = None
+        # host -> device upload of a minibatch (dpp.py:916-917): only the tensors the path reads, on a copy stream,
+        # network inputs first -- the encoders start while the loss-stage images are still crossing PCIe
+        self.upload_all_inputs = os.environ.get('CLSLAM_UPLOAD_ALL', '0') == '1'
+        self._copy_stream = None
 
     # ============================================================
     # Data-parallel replay minibatch (new functionality; the reference has no multi-GPU adaptation)
@@ -338,10 +342,11 @@ class DepthPosePrediction:
                 # forward copies the loss to pinned host memory behind an event; backward and a device-
                 # guarded Adam (no-op when the loss is NaN) are enqueued, and only then does the host wait
                 # for THAT event -- the GPU still has the whole backward queued while the host goes on.
-                self.optimizer.loss_guard = losses['loss']
+                self.optimizer.loss_guard = self._losses_dev[17:18]
                 self.optimizer.step()
                 self.optimizer.loss_guard = None
-                self._raise_on_nan(losses, undo_step=True, staged=True)
+                losses = self._staged_losses()
+                self._raise_on_nan(losses, undo_step=True)
         else:
             self._set_eval()
             self.engine.pack_if_needed()
@@ -510,44 +515,107 @@ class DepthPosePrediction:
                                f'({loss_sample_weights.numel()}) at non-singleton dimension 0')
         return w, w
 
+    # the tensors of the sample dict the path reads, in the order the step needs them
+    UPLOAD_FIRST = [('rgb_aug', 0, 0), ('rgb_aug', -1, 0), ('rgb_aug', 1, 0)]
+    UPLOAD_REST = [('camera_matrix', 0), ('inv_camera_matrix', 0), ('relative_distance', 0), ('relative_distance', 1),
+                   ('rgb', -1, 0), ('rgb', 1, 0), ('rgb', 0, 0), ('rgb', 0, 1), ('rgb', 0, 2), ('rgb', 0, 3)]
+
+    def _upload(self, inputs: Dict[Any, Tensor]):
+        """Move the caller's dict to the device in place like dpp.py:916-917 -- but only the 13 entries the path reads
+        (9 image planes of 24; CLSLAM_UPLOAD_ALL=1 / upload_all_inputs moves every entry like the reference), and
+        asynchronously: the copies run on their own stream (pinned sources: DataLoader(pin_memory=True), slam.py:86),
+        the three network inputs first.  Returns the events (depth-net input there, pose-net inputs there, everything
+        there) for the engine's streams to wait on, or None when nothing had to move."""
+        dev = self.device
+        todo = [k for k in self.UPLOAD_FIRST + self.UPLOAD_REST if k in inputs and inputs[k].device != dev]
+        extra = [k for k in inputs if self.upload_all_inputs and k not in self.UPLOAD_FIRST + self.UPLOAD_REST
+                 and isinstance(inputs[k], Tensor) and inputs[k].device != dev]
+        if not todo and not extra:
+            return None
+        if dev.type != 'cuda':
+            for k in todo + extra:
+                inputs[k] = inputs[k].to(dev)
+            return None
+        if self._copy_stream is None:
+            self._copy_stream = torch.cuda.Stream(device=dev)
+        cur = torch.cuda.current_stream(dev)
+        cs = self._copy_stream
+        cs.wait_stream(cur)                 # (allocator) blocks freed on the caller's stream may be handed out here
+        users = [cur] + [st for st in (self.engine.side_stream, self.engine.wg_stream) if st is not None]
+        def copy(k):
+            t = inputs[k].to(dev, non_blocking=True)
+            for st in users:                # consumed on the engine's streams: keep the block until they are past it
+                t.record_stream(st)
+            inputs[k] = t
+        with torch.cuda.stream(cs):
+            evs = []
+            for group in ([self.UPLOAD_FIRST[0]], self.UPLOAD_FIRST[1:]):   # depth-net input, then the pose pairs' frames
+                for k in group:
+                    if k in todo:
+                        copy(k)
+                ev = torch.cuda.Event()
+                ev.record(cs)
+                evs.append(ev)
+            for k in todo + extra:
+                if k not in self.UPLOAD_FIRST:
+                    copy(k)
+            all_ev = torch.cuda.Event()
+            all_ev.record(cs)
+        return evs[0], evs[1], all_ev
+
     def _process_batch(self, inputs: Dict[Any, Tensor], loss_sample_weights: Optional[Tensor] = None,
                        use_online: bool = False, train: bool = False, graphed: bool = False, copy_inputs: bool = True,
                        reuse_frozen: bool = False, want_outputs: bool = True):
+        ready = None
         if not reuse_frozen:             # steps 2..S of one adapt() call see the dict this loop already moved
-            for key, val in inputs.items():  # mutates the caller's dict, like dpp.py:916-917
-                inputs[key] = val.to(self.device)
+            ready = self._upload(inputs)
         B = inputs['rgb_aug', 0, 0].shape[0]
         sample_w, smooth_w = self._sample_weights(B, loss_sample_weights, local=not train)
         if graphed:
+            if ready is not None:
+                torch.cuda.current_stream(self.device).wait_event(ready[2])
             outputs, losses = self.engine.train_step_graphed(inputs, sample_w=sample_w, smooth_w=smooth_w,
                                                              noise=self._injected_noise, copy_inputs=copy_inputs,
                                                              reuse_frozen=reuse_frozen, want_outputs=want_outputs)
         else:
             outputs, losses = self.engine.forward(inputs, train=train, sample_w=sample_w, smooth_w=smooth_w,
-                                                  noise=self._injected_noise, reuse_frozen=reuse_frozen)
+                                                  noise=self._injected_noise, reuse_frozen=reuse_frozen, inputs_ready=ready)
         if self._dp is not None and train:
             # only training steps are collective: predict() / adapt(online, None) on one rank (slam.py:178 on the
             # rank that holds the online frame) must not pair up with another rank's gradient exchange
             self._dp['dist'].all_reduce(losses, group=self._dp['group'])
-        loss_dict = self.engine.losses_dict(losses)
-        if not train:
-            self._raise_on_nan(loss_dict)
-        elif self.device.type == 'cuda':   # training steps check after the optimizer launch (see adapt)
+        self._losses_dev = losses
+        if self.device.type == 'cuda':
+            # ONE device->host copy of the 18 loss scalars per step (the NaN check of dpp.py:1115-1118 needs the loss
+            # on the host anyway): the returned dict holds HOST tensors, so the caller's per-key `.cpu()` / `.item()`
+            # (slam.py:186-188: one per key) cost nothing instead of a stream synchronisation each
             if self._loss_host is None:
-                self._loss_host = torch.empty(1, dtype=torch.float32, pin_memory=True)
+                self._loss_host = torch.empty(18, dtype=torch.float32, pin_memory=True)
                 self._loss_event = torch.cuda.Event()
-            self._loss_host.copy_(loss_dict['loss'], non_blocking=True)
+            self._loss_host.copy_(losses, non_blocking=True)
             self._loss_event.record()
+            if not train:
+                self._loss_event.synchronize()
+                loss_dict = self.engine.losses_dict(self._loss_host.clone())
+                self._raise_on_nan(loss_dict)
+            else:
+                loss_dict = None         # adapt() builds it after the optimizer launch (see there)
+        else:
+            loss_dict = self.engine.losses_dict(losses)
+            if not train:
+                self._raise_on_nan(loss_dict)
         return outputs, loss_dict
 
-    def _raise_on_nan(self, loss_dict, undo_step: bool = False, staged: bool = False) -> None:
-        """dpp.py:1115-1118 (the step's only host wait).  staged: the loss was copied to pinned memory by
-        the forward; wait for that copy only, not for the stream."""
-        if staged and self.device.type == 'cuda':
-            self._loss_event.synchronize()
-            value = float(self._loss_host[0])
-        else:
-            value = loss_dict['loss'].item()
+    def _staged_losses(self) -> Dict[str, Tensor]:
+        """the training step's loss dict: waits for the forward's staged copy only, not for the stream"""
+        if self.device.type != 'cuda':
+            return self.engine.losses_dict(self._losses_dev)
+        self._loss_event.synchronize()
+        return self.engine.losses_dict(self._loss_host.clone())
+
+    def _raise_on_nan(self, loss_dict, undo_step: bool = False) -> None:
+        """dpp.py:1115-1118"""
+        value = float(loss_dict['loss'])
         if np.isnan(value):
             if undo_step:   # the guarded Adam launch did not touch weights or moments
                 self.engine.adam_step_count -= 1

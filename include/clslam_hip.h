@@ -207,6 +207,14 @@ int clslam_disp_mean_pyramid(const float* const* disp, float* psum, int batch, i
 int clslam_photo_automask_pyramid(const float* warped, const float* target, const float* idmap, const float* noise,
                                   unsigned char* sel, float* coef_sel, float* partial, int batch, int H, int W,
                                   void* stream);
+/* The same with the tie-break noise of dpp.py:1055-1056 drawn INSIDE the kernel (Philox4x32-10 + Box-Muller, x 1e-5):
+ * element ((scale * B + b) * H * W + pixel) of draw `offset`, key `seed` (non-zero).  Timing / production runs; parity
+ * runs inject captured tensors through clslam_photo_automask_pyramid.  clslam_tie_break_noise writes the pairs
+ * (n_id(-1), n_id(+1)) of elements [0, npix) of the same stream to out[2 * npix] (tests, inspection).            */
+int clslam_photo_automask_pyramid_rng(const float* warped, const float* target, const float* idmap, unsigned long long seed,
+                                      unsigned long long offset, unsigned char* sel, float* coef_sel, float* partial, int batch,
+                                      int H, int W, void* stream);
+int clslam_tie_break_noise(float* out, size_t npix, unsigned long long seed, unsigned long long offset, void* stream);
 /* LDS-tiled fused loss backward on coef_sel; dp_partial [4][B][clslam_loss_bwd2_blocks][24].                */
 int clslam_loss_bwd2_blocks(int H, int W);
 int clslam_loss_bwd2_pyramid(const float* const* disp, const unsigned char* sel, const float* coef_sel, const float* warped,

@@ -174,3 +174,43 @@ def test_loss_stage_matches_oracle(backend, B, H, W, max_depth, aligned, pyramid
     pg = pose.grad
     assert rel_err(got['dpose'].cpu()[:, :6], pg[:, :6]) < (2e-2 if any_flip else 2e-4)
     assert float(got['dpose'].cpu()[:, 6:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_in_kernel_tie_break_noise(backend):
+    """dpp.py:1055-1056 inside the kernel (Philox4x32-10 + Box-Muller): N(0, 1e-5) per identity channel, reproducible per
+    (seed, draw offset), fresh per offset; the fused photometric/automask kernel fed by the generator selects exactly
+    what it selects when the same stream is injected as a tensor."""
+    dev = use_backend(backend)
+    n = 200000
+    a = ops.tie_break_noise(torch.empty(n, 2, device=dev), seed=1234567, offset=3).cpu()
+    b = ops.tie_break_noise(torch.empty(n, 2, device=dev), seed=1234567, offset=3).cpu()
+    c = ops.tie_break_noise(torch.empty(n, 2, device=dev), seed=1234567, offset=4).cpu()
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    z = a.double() / 1e-5
+    assert abs(float(z.mean())) < 0.01 and abs(float(z.std()) - 1) < 0.01
+    assert abs(float((z ** 4).mean()) - 3) < 0.1                                   # kurtosis of a normal
+    assert abs(float((z[:, 0] * z[:, 1]).mean())) < 0.01 and abs(float((z * (c.double() / 1e-5)).mean())) < 0.01
+    assert float(z.abs().max()) < 6.5
+    # the fused kernel: generator == injected tensor of the same stream
+    B, H, W = 2, 24, 80
+    g = torch.Generator().manual_seed(3)
+    tgt = torch.rand(B, 3, H, W, generator=g)
+    warped = (tgt[None, None] + 0.002 * torch.randn(4, 2, B, 3, H, W, generator=g)).clamp(0, 1).contiguous()
+    idmap = 0.0005 + 1e-5 * torch.rand(2, B, H, W, generator=g)                    # near-ties decided by the noise
+    stream = ops.tie_break_noise(torch.empty(4 * B * H * W, 2, device=dev), seed=99, offset=7)
+    noise = stream.view(4, B, H * W, 2).permute(0, 1, 3, 2).reshape(4, B, 2, H, W).contiguous()
+    nblk = ops.automask_blocks(H, W)
+    outs = []
+    for mode in ('rng', 'tensor', 'none'):
+        sel = torch.zeros(4, B, H, W, dtype=torch.uint8, device=dev)
+        coef = torch.zeros(4, B, 9, H, W, device=dev)
+        partial = torch.zeros(4, B, nblk, device=dev)
+        if mode == 'rng':
+            ops.photo_automask_pyramid_rng(warped.to(dev), tgt.to(dev), idmap.to(dev), 99, 7, sel, coef, partial, B, H, W)
+        else:
+            ops.photo_automask_pyramid(warped.to(dev), tgt.to(dev), idmap.to(dev), noise if mode == 'tensor' else None, sel, coef,
+                                       partial, B, H, W)
+        outs.append((sel.cpu(), partial.cpu(), coef.cpu()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+    assert not torch.equal(outs[0][0], outs[2][0])                                 # the noise does decide near-ties
