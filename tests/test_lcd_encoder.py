@@ -75,3 +75,36 @@ def test_feature_encoder_latency_on_gpu(capsys):
         with capsys.disabled():
             print(f'\n[lcd] MobileNetV3-small features {H}x{W} B=1: {ms:.3f} ms per call')
         assert ms < 10.0
+
+
+def test_lcd_pin_script_is_honest():
+    """tests/golden/make_lcd_golden.py pins oracle/mobilenet.py against the real torchvision the first time a build
+    container has it; until then it must say PARITY UNPINNED (exit 3) -- and once tests/golden/lcd_features.npz exists
+    the oracle is held to it."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    import numpy as np
+    gold = Path(__file__).parent / 'golden' / 'lcd_features.npz'
+    try:
+        import torchvision  # noqa: F401
+        have_tv = True
+    except Exception:  # noqa: BLE001
+        have_tv = False
+    if not have_tv:
+        r = subprocess.run([sys.executable, str(gold.parent / 'make_lcd_golden.py')], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 3 and 'PARITY UNPINNED' in r.stdout, r.stdout + r.stderr
+    if gold.exists():                                    # a container with torchvision + weights has pinned it
+        import os
+        wfile = os.environ.get('CLSLAM_MOBILENETV3_WEIGHTS')
+        if not wfile or not Path(wfile).exists():
+            pytest.skip('golden features exist but the ImageNet checkpoint is not on this machine')
+        from oracle.mobilenet import MobileNetV3SmallFeatures, feature_encoder
+        real = torch.load(wfile, map_location='cpu')
+        m = MobileNetV3SmallFeatures()
+        m.load_state_dict({k: v for k, v in real.items() if k.startswith('features.')})
+        g = np.load(gold)
+        for i in range(2):
+            n, H, W, seed = (int(v) for v in g[f'params_{i}'])
+            img = synth.make_batch(n, H, W, seed=seed)['rgb', 1, 0]
+            assert rel_err(feature_encoder(m.eval(), img), torch.from_numpy(g[f'features_{i}'])) < 1e-6
