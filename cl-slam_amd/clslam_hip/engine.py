@@ -243,6 +243,17 @@ class Engine:
         self._modules_stale = False
         self._packed_version = self._module_version()
 
+    @torch.no_grad()
+    def install_weights(self, flat: torch.Tensor, adam_step_count: Optional[int] = None) -> None:
+        """Replace the whole trainable arena (compute layout, `layout.size` floats) -- the receiving side of a weight
+        broadcast (clslam_hip.async_mode).  Module parameters are re-materialised lazily like after an optimizer step."""
+        self.pack_if_needed()
+        self.wait_training()
+        self.w.copy_(flat.reshape(-1)[:self.layout.size])
+        if adam_step_count is not None:
+            self.adam_step_count = int(adam_step_count)
+        self._modules_stale = True
+
     def wview(self, name: str) -> torch.Tensor:
         self.wait_training()
         for n, off, shape in self.layout.entries:
