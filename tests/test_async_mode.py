@@ -12,7 +12,7 @@ import torch
 import torch.multiprocessing as mp
 
 ROOT = Path(__file__).resolve().parents[1]
-H, W, B, FRAMES, EVERY = 64, 128, 2, 6, 2
+H, W, B, FRAMES, EVERY = 64, 128, 2, 3, 1
 
 
 def _worker(rank, world, port, out_dir):
@@ -63,12 +63,12 @@ def test_inference_replica_follows_the_trainer(tmp_path):
     inf = torch.load(tmp_path / 'rank0.pt')
     trn = torch.load(tmp_path / 'rank1.pt')
     snaps = {r['frame']: r['snapshot'] for r in trn['log'] if 'snapshot' in r}
-    assert sorted(snaps) == [1, 3, 5]
+    assert sorted(snaps) == [0, 1, 2]
     assert all(torch.isfinite(torch.tensor(r['loss'])) for r in trn['log'])
-    assert not torch.equal(snaps[1], snaps[3])                       # the trainer really moves
+    assert not torch.equal(snaps[0], snaps[2])                       # the trainer really moves
     # after flush() the replica holds the trainer's LAST snapshot, bit for bit
-    assert inf['final']['weights_frame'] == 5 and inf['final']['installs'] == 3
-    assert torch.equal(inf['final']['w'], snaps[5])
+    assert inf['final']['weights_frame'] == 2 and inf['final']['installs'] == 3
+    assert torch.equal(inf['final']['w'], snaps[2])
     sys.path.insert(0, str(ROOT / 'tests'))
     for rec in inf['log']:
         f, wf = rec['frame'], rec['weights_frame']
