@@ -26,6 +26,7 @@ class OraclePredictor:
         self.velocity_loss_scaling = velocity_loss_scaling
         self.reference_quirks = reference_quirks
         self.scales = (0, 1, 2, 3)
+        self.forced_sel, self.last_combined, self.last_sel = None, {}, {}
         self.frame_ids = (0, -1, 1)
         # dpp.py:129-137 (dict insertion order defines the optimizer's parameter order)
         self.models = {
@@ -98,7 +99,12 @@ class OraclePredictor:
             if noise is not None:  # dpp.py:1055-1056, injected instead of drawn
                 idl = idl + noise[s]
             combined = torch.cat((idl, rp), 1)  # dpp.py:1057
-            to_opt, _ = torch.min(combined, dim=1)
+            to_opt, argmin = torch.min(combined, dim=1)
+            # test hooks (tests/test_backward_parity.py): what was selected, and optionally a selection imposed from
+            # outside (the kernel path's) so that the remaining gradient difference can be attributed
+            self.last_combined[s], self.last_sel[s] = combined.detach(), argmin.detach()
+            if self.forced_sel is not None:
+                to_opt = torch.gather(combined, 1, self.forced_sel[s].long().unsqueeze(1)).squeeze(1)
             rl = (to_opt.mean(2).mean(1) * sample_weights).sum()  # dpp.py:1073
             losses[f'reprojection_loss/scale_{s}'] = rl
             disp = outputs['disp', s]

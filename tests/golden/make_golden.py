@@ -222,6 +222,38 @@ def main() -> None:
         # fraction of pixels whose automask picks a reprojection (sanity of the fixture)
         np.savez_compressed(OUT / f'{case}.npz', **rec)
         print(case, 'keys', len(rec), 'loss', float(all_steps[-1][1]['loss']))
+    # ---- 192x640 (the benchmark resolution), B=1, one adapt step: checksums only -------------------
+    if '--no-full' not in sys.argv:
+        H2, W2, B2 = 192, 640, 1
+        p = build_reference(H2, W2, B2, OUT / '_tmp_log')
+        for name, m in p.models.items():
+            m.load_state_dict(synth.fill_state_dict(m.state_dict(), 0, name))
+        batch = synth.make_batch(B2, H2, W2, seed=5)
+        noise = synth.make_noise(B2, H2, W2, seed=15)
+        inj.queue = [noise[s] for s in range(4)]
+        outputs, losses = p.adapt(None, {k: v.clone() for k, v in batch.items()}, steps=1)
+        rec = {'params': np.array([H2, W2, B2, 5, 15], np.int64)}
+        for k, v in losses.items():
+            rec['loss/' + k] = np.array(float(v.detach()))
+        for k, v in outputs.items():
+            name = 'out/' + '_'.join(str(x) for x in k)
+            v = v.detach()
+            if v.numel() <= 64:
+                rec[name] = v.numpy().copy()
+            else:      # mean, L2 norm, a strided sample of 512 values
+                rec[name + '_mean'] = np.array(v.double().mean().item())
+                rec[name + '_l2'] = np.array(v.double().norm().item())
+                flat = v.reshape(-1)
+                rec[name + '_sample'] = flat[:: max(1, flat.numel() // 512)][:512].numpy().copy()
+        names = [(mn, n) for mn, m in p.models.items() for n, _ in m.named_parameters()]
+        params = [q for m in p.models.values() for q in m.parameters()]
+        for (mn, n), q in zip(names, params):
+            if q.grad is not None:
+                g = q.grad.detach()
+                rec[f'gradnorm/{mn}/{n}'] = np.array(g.double().norm().item())
+                rec[f'gradslice/{mn}/{n}'] = g.reshape(-1)[:64].numpy().copy()
+        np.savez_compressed(OUT / 'adapt_full_b1.npz', **rec)
+        print('adapt_full_b1 keys', len(rec), 'loss', float(losses['loss']))
     torch.randn = inj.orig
     import shutil
     shutil.rmtree(OUT / '_tmp_log', ignore_errors=True)

@@ -95,3 +95,24 @@ def test_b5_step_is_the_sum_of_its_shards_and_deterministic():
     assert l2 < 2e-2 and mx < 5e-2, (l2, mx)
     for k in ('loss', 'velocity_loss', 'reprojection_loss/scale_0', 'smooth_loss/scale_0', 'reg_loss/scale_3'):
         assert abs(float(l_a[k]) + float(l_b[k]) - float(l_full[k])) < 2e-5 * max(abs(float(l_full[k])), 1e-4), k
+
+
+def test_b1_step_matches_reference_golden_at_full_size():
+    """192x640: the HIP path against vectors produced by the REAL reference at this size (tests/golden/make_golden.py,
+    adapt_full_b1.npz) -- not only against the oracle."""
+    import math
+    from clslam_hip.engine import TrainableLayout
+    from helpers import load_golden
+    from test_oracle_golden import _check_full_size
+    use_backend('hip')
+    g = load_golden('adapt_full_b1')
+    H, W, B, seed_b, seed_n = (int(v) for v in g['params'])
+    p = make_predictor(H, W, B)
+    p.set_tie_break_noise(synth.make_noise(B, H, W, seed=seed_n))
+    out, losses = p.adapt(None, synth.make_batch(B, H, W, seed=seed_b), steps=1)
+    eng = p.engine
+    eng.wait_training()
+    grads = {name: TrainableLayout.to_reference(eng.g[off:off + math.prod(shape)], shape).cpu()
+             for name, off, shape in eng.layout.entries}
+    # step-0 outputs and losses at the 1e-4 bar; gradient norms carry the selection flips (tests/test_backward_parity.py)
+    _check_full_size(g, out, losses, grads, 1e-4, 1e-4, 3e-2)

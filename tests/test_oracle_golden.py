@@ -102,3 +102,51 @@ def test_adapt_matches_reference(case, B, steps):
     osd = p.optimizer.state_dict()
     assert sorted(osd['state'].keys()) == list(g['opt_state_ids'])
     assert len(osd['param_groups'][0]['params']) == int(g['opt_num_params']) == 160
+
+
+def _check_full_size(g, outputs, losses, grads, tol_out, tol_loss, tol_grad):
+    """adapt_full_b1.npz: 192x640, B=1, one adapt step of the REAL reference -- means / L2 norms / strided samples of
+    every output plane, every loss scalar, norm + 64-entry slice of the 36 gradients."""
+    n = 0
+    for name, ref in g.items():
+        if name.startswith('loss/'):
+            got = float(losses[name[5:]])
+            assert abs(got - float(ref)) <= tol_loss * max(abs(float(ref)), 1e-3), (name, got, float(ref))
+        elif name.startswith('out/'):
+            kname = name[4:]
+            for suffix in ('_mean', '_l2', '_sample', ''):
+                if suffix and kname.endswith(suffix):
+                    kname = kname[:-len(suffix)]
+                    break
+            key = _key(kname)
+            v = outputs[key[0] if len(key) == 1 else key].detach().cpu()
+            if suffix == '_mean':
+                got = v.double().mean().item()
+            elif suffix == '_l2':
+                got = v.double().norm().item()
+            elif suffix == '_sample':
+                flat = v.reshape(-1)
+                got = flat[:: max(1, flat.numel() // 512)][:512].numpy()
+            else:
+                got = v.numpy()
+            assert rel_err(got, ref) < tol_out, (name, rel_err(got, ref))
+            n += 1
+        elif name.startswith('gradnorm/') and grads is not None:
+            gn = float(ref)
+            got = grads[name[9:]]
+            assert abs(float(got.double().norm()) - gn) <= tol_grad * gn + 2e-6, (name, float(got.double().norm()), gn)
+    assert n >= 50
+
+
+def test_adapt_full_size_matches_reference():
+    g = load_golden('adapt_full_b1')
+    H2, W2, B2, seed_b, seed_n = (int(v) for v in g['params'])
+    o = make_oracle(H2, W2, B2)
+    batch = synth.make_batch(B2, H2, W2, seed=seed_b)
+    noise = synth.make_noise(B2, H2, W2, seed=seed_n)
+    o.set_adapt()
+    out, losses = o.process_batch(batch, noise, None)
+    o.optimizer.zero_grad()
+    losses['loss'].backward()
+    grads = {f'{m}/{k}': prm.grad for m in ('depth_decoder', 'pose_decoder') for k, prm in o.models[m].named_parameters()}
+    _check_full_size(g, out, {k: v.detach() for k, v in losses.items()}, grads, 2e-5, 2e-6, 2e-5)
