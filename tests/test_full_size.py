@@ -115,4 +115,4 @@ def test_b1_step_matches_reference_golden_at_full_size():
     grads = {name: TrainableLayout.to_reference(eng.g[off:off + math.prod(shape)], shape).cpu()
              for name, off, shape in eng.layout.entries}
     # step-0 outputs and losses at the 1e-4 bar; gradient norms carry the selection flips (tests/test_backward_parity.py)
-    _check_full_size(g, out, losses, grads, 1e-4, 1e-4, 3e-2)
+    _check_full_size(g, out, losses, grads, 1e-4, 1e-4, 3e-2, tol_warp=5e-4)
