@@ -24,14 +24,18 @@ for ctr in FETCH_SIZE WRITE_SIZE; do
     (cd /tmp && CLSLAM_SIDE_STREAM=0 rocprofv3 --pmc $ctr -d /tmp/pmc_$ctr -o run -- python $OLDPWD/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-also > /tmp/pmc_$ctr.log 2>&1)
     db=$(ls /tmp/pmc_$ctr/*/*.db /tmp/pmc_$ctr/*.db 2>/dev/null | head -1)
     python tools/pmc_summary.py $db conv > $OUT/${TAG}_pmc_$ctr.txt 2>&1
+    eval "DB_$ctr=$db"
 done
+# L2-miss traffic per launch of every conv kernel, keyed by kernel name: bench.py's roofline.traffic reads THIS file
+python tools/pmc_traffic.py $DB_FETCH_SIZE $DB_WRITE_SIZE $OUT/${TAG}_pmc_traffic.json > $OUT/${TAG}_pmc_traffic.log 2>&1
 brief() { python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print({k: d.get(k) for k in ('value', 'unit', 'ms_per_step', 'also')}, d['config']['workload'][:70])"; }
 {
   for r in 0 2 32; do echo "== 192x640 replay $r"; python bench.py --replay $r --steps 20 --warmup 5 --no-cpu-baseline | brief; done
   echo "== 192x640 replay 4, uniform-random images"; python bench.py --random-images --steps 20 --warmup 5 --no-cpu-baseline | brief
   echo "== 384x1280 replay 8"; python bench.py --height 384 --width 1280 --replay 8 --steps 10 --warmup 3 --no-cpu-baseline | brief
 } > $OUT/${TAG}_other_configs.txt 2>&1
-BENCH_WGRAD=1 python tools/bench_conv.py > $OUT/${TAG}_conv_microbench.txt 2>&1
+BENCH_WGRAD=1 python tools/bench_conv.py 5 30,31,32,33 > $OUT/${TAG}_conv_microbench.txt 2>&1
+BENCH_WGRAD=0 python tools/bench_conv.py 1 30,31,32,33 > $OUT/${TAG}_conv_microbench_b1.txt 2>&1
 python tools/bench_small.py > $OUT/${TAG}_small_kernels.txt 2>&1
 python tools/bench_reduce.py > $OUT/${TAG}_reduce.txt 2>&1
 echo done
