@@ -159,6 +159,10 @@ def main():
                 full[k] = torch.rand(full[k].shape, generator=g)
     shard = {k: v[offset:offset + Bl].contiguous() for k, v in full.items()}
     batch = {k: v.to(dev) for k, v in shard.items()}
+    if args.random_images:
+        # training the untrained synthetic network on noise is degenerate (the disparity collapses to 0 within tens of steps
+        # and the reference's NaN guard fires, dpp.py:1115): the timing run keeps the weights in place -- same kernels, lr ~ 0
+        p.optimizer.param_groups[0]['lr'] = 1e-12
 
     S = args.adapt_steps
 
@@ -301,7 +305,7 @@ def main():
             'metric': 'online-adapt frames/sec @192x640 (1 triplet + K replay)',
             'value': round(value, 3), 'unit': 'frames/s', 'n_gpus': N, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32', 'data': 'synthetic (uniform-random images)' if args.random_images else 'synthetic',
+            'dtype': 'f32', 'data': 'synthetic (uniform-random images, lr 1e-12)' if args.random_images else 'synthetic',
             'config': {'workload': f'DepthPosePrediction.adapt(steps={S}), {H}x{W}, 1 online + K={K} replay triplets '
                                    f'(global batch {B}); ResNet-18 depth+pose nets, closed-form random-init weights; '
                                    f'a frame = {FRAME_TRIPLETS} triplets (value = steps/s * B/{FRAME_TRIPLETS})',

@@ -31,7 +31,7 @@ python tools/pmc_traffic.py $DB_FETCH_SIZE $DB_WRITE_SIZE $OUT/${TAG}_pmc_traffi
 brief() { python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print({k: d.get(k) for k in ('value', 'unit', 'ms_per_step', 'also')}, d['config']['workload'][:70])"; }
 {
   for r in 0 2 32; do echo "== 192x640 replay $r"; python bench.py --replay $r --steps 20 --warmup 5 --no-cpu-baseline | brief; done
-  echo "== 192x640 replay 4, uniform-random images"; python bench.py --random-images --steps 20 --warmup 5 --no-cpu-baseline | brief
+  echo "== 192x640 replay 4, uniform-random images"; python bench.py --random-images --steps 20 --warmup 5 --no-cpu-baseline --no-also | brief
   echo "== 384x1280 replay 8"; python bench.py --height 384 --width 1280 --replay 8 --steps 10 --warmup 3 --no-cpu-baseline | brief
 } > $OUT/${TAG}_other_configs.txt 2>&1
 BENCH_WGRAD=1 python tools/bench_conv.py 5 30,31,32,33 > $OUT/${TAG}_conv_microbench.txt 2>&1
