@@ -80,6 +80,10 @@ _SIGNATURES = {
     'clslam_photo_automask_pyramid': [fptr, fptr, fptr, fptr, fptr, fptr, fptr, i32, i32, i32, C.c_void_p],
     'clslam_photo_automask_pyramid_rng': [fptr, fptr, fptr, C.c_uint64, C.c_uint64, fptr, fptr, fptr, i32, i32, i32, C.c_void_p],
     'clslam_tie_break_noise': [fptr, C.c_size_t, C.c_uint64, C.c_uint64, C.c_void_p],
+    'clslam_smooth_intended_chunks': [],
+    'clslam_smooth_intended_fwd': [C.POINTER(fptr), C.POINTER(fptr), fptr, i32, i32, i32, C.c_void_p],
+    'clslam_smooth_intended_finalize': [fptr, fptr, fptr, fptr, fptr, i32, i32, i32, C.c_float, C.c_void_p],
+    'clslam_smooth_intended_bwd': [C.POINTER(fptr), C.POINTER(fptr), fptr, fptr, C.POINTER(fptr), i32, i32, i32, C.c_float, C.c_void_p],
     'clslam_loss_bwd2_blocks': [i32, i32],
     'clslam_loss_bwd2_pyramid': [C.POINTER(fptr), fptr, fptr, fptr, fptr, fptr, fptr, fptr, fptr, fptr, fptr, fptr, i32, i32, i32,
                                  C.c_float, C.c_float, C.c_void_p],

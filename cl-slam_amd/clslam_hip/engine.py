@@ -101,8 +101,9 @@ class Engine:
                               'needs a GPU and has no CPU fallback')
         if height % 32 or width % 32:
             raise ValueError('height and width must be multiples of 32 (five stride-2 stages)')
-        if not reference_quirks:
-            raise NotImplementedError('only the reference smoothness behaviour (SURVEY.md 0.3) is implemented')
+        # reference_quirks=False: the per-sample edge-aware smoothness the reference evidently meant instead of
+        # the flattened-batch behaviour of dpp.py:1148-1176; opt-in, parity runs use the default
+        self.smooth_intended = not reference_quirks
         if min_depth is None and max_depth is not None:
             raise ValueError('min_depth is None')        # disp_to_depth, utils.py:134-135
         self.H, self.W, self.device = height, width, device
@@ -577,7 +578,7 @@ class Engine:
             ops.photo_automask_pyramid_rng(ws.warped, rgb[0], ws.idmap, self.noise_seed, self.noise_draws, ws.sel,
                                            ws.coef if train else None, ws.partial, B, H, W)
         ops.disp_mean_pyramid(ws.disp, ws.means, H, W)
-        n_smooth = 0 if smooth_w is None else int(smooth_w.numel())
+        n_smooth = 0 if (smooth_w is None or self.smooth_intended) else int(smooth_w.numel())
         if n_smooth and not (n_smooth < (W >> 3) - 1):
             raise ClslamError('reference smoothness layout needs batch < width/8 - 1')
         aux = getattr(ws, 'smooth_aux', None)
@@ -590,8 +591,14 @@ class Engine:
         ops.loss_finalize([ws.partial[s] for s in range(4)], ws.disp, rgb0, [ws.means[s] for s in range(4)], ws.pose, d0, d1,
                           sample_w, smooth_w if n_smooth else None, ws.losses, aux if n_smooth else None, B, ws.nblk, H, W,
                           n_smooth, self.smooth_scale, self.vel_scale)
+        if self.smooth_intended:
+            if getattr(ws, 'si_partial', None) is None:
+                ws.si_partial = torch.empty(4, B, ops.smooth_intended_chunks(), device=self.device)
+                ws.si_aux = torch.empty(4, B, 2, device=self.device)
+            ops.smooth_intended_fwd(ws.disp, rgb0, ws.si_partial, H, W)
+            ops.smooth_intended_finalize(ws.si_partial, ws.means, sample_w, ws.losses, ws.si_aux, B, H, W, self.smooth_scale)
         ws.ctx = SimpleNamespace(rgb=rgb, K=K, Kinv=Kinv, d0=d0, d1=d1, sample_w=sample_w, n_smooth=n_smooth,
-                                 aux=aux if n_smooth else None, B=B)
+                                 aux=aux if n_smooth else None, B=B, rgb0=rgb0)
         ws.frozen_valid = True      # encoder features + identity maps of THESE inputs and encoder weights are held
         return self._outputs(ws, B), ws.losses
 
@@ -685,6 +692,8 @@ class Engine:
         ops.loss_bwd2_pyramid(ws.disp, ws.sel, ws.coef, ws.warped, c.rgb[0], c.rgb[-1], c.rgb[1], c.Kinv, ws.P, c.sample_w,
                               t.ddisp_up, t.dp_partial, self.min_depth, self.max_depth)
         ops.disp_grad_pyramid(t.ddisp_up, ws.disp, c.aux if c.n_smooth else None, c.n_smooth, t.dz_disp, H, W)
+        if self.smooth_intended:
+            ops.smooth_intended_bwd(ws.disp, c.rgb0, ws.si_aux, c.sample_w, t.dz_disp, H, W, self.smooth_scale)
         ops.pose_bwd(t.dp_partial, 4, t.nb2, ws.pose, c.K, c.d0, c.d1, c.sample_w, self.vel_scale, t.dpose)
         side = self.side_stream if (self.use_side_stream and self.side_stream is not None) else None
         if side is not None:

@@ -447,6 +447,25 @@ def tie_break_noise(out, seed, offset):
     return out
 
 
+def smooth_intended_chunks() -> int:
+    return _lib.get_lib().cdll.clslam_smooth_intended_chunks()
+
+
+def smooth_intended_fwd(disps, rgb0, partial, H, W):
+    _lib.get_lib().call('clslam_smooth_intended_fwd', _ptr4(disps), _ptr4(rgb0), _p(partial), disps[0].shape[0], H, W,
+                        _stream(partial))
+
+
+def smooth_intended_finalize(partial, means, sample_w, losses, aux, batch, H, W, smooth_scale):
+    _lib.get_lib().call('clslam_smooth_intended_finalize', _p(partial), _p(means), _p(sample_w), _p(losses), _p(aux), batch, H, W,
+                        float(smooth_scale), _stream(losses))
+
+
+def smooth_intended_bwd(disps, rgb0, aux, sample_w, dz, H, W, smooth_scale):
+    _lib.get_lib().call('clslam_smooth_intended_bwd', _ptr4(disps), _ptr4(rgb0), _p(aux), _p(sample_w), _ptr4(dz),
+                        disps[0].shape[0], H, W, float(smooth_scale), _stream(aux))
+
+
 def loss_bwd2_blocks(H, W) -> int:
     return _lib.get_lib().cdll.clslam_loss_bwd2_blocks(H, W)
 

@@ -1026,3 +1026,134 @@ extern "C" int clslam_disp_grad_pyramid(const float* ddisp_up, const float* cons
                        smooth_aux, n_smooth, batch, H, W, make_pyramid(disp, H, W), dzp);
     return check_launch("disp_grad_pyramid");
 }
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// Opt-in "intended" smoothness: the per-sample edge-aware term the reference evidently meant
+// (monodepth2), instead of the flattened-batch behaviour of dpp.py:1148-1176 that parity reproduces by default:
+//   sm_b = mean_{y, x<w-1} |n(y,x) - n(y,x+1)| exp(-mean_c |I(y,x) - I(y,x+1)|) + the same along y,   n = disp / (mean(disp) + 1e-7)
+// n is disp times a positive per-sample scalar, so sm_b = inv_b * T_b with T_b the same sums over the raw disparity.
+// Three small kernels around the existing stage: chunked partial sums of T (fixed order), a one-block finalize that adds
+// the terms to the 18 loss scalars and keeps (inv_b, T_b) for the backward, and the gradient added into dz of the
+// disparity heads:  d sm_b / d disp(p) = inv_b * sum_{edges at p} sign * e / norm  -  T_b * inv_b^2 / (h w).
+namespace clslam {
+
+constexpr int SI_CHUNKS = 32;
+
+__device__ __forceinline__ float si_edge_weight(const float* __restrict__ img, int hw, int p, int q) {
+    float g = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) g += fabsf(img[(size_t)c * hw + p] - img[(size_t)c * hw + q]);
+    return expf(-(g / 3.f));
+}
+
+struct SiPtrs { const float* rgb0[4]; };
+struct SiDz { float* dz[4]; };
+
+__global__ __launch_bounds__(256) void smooth_intended_fwd_kernel(Pyramid pyr, SiPtrs im, float* __restrict__ partial, int B) {
+    __shared__ float red[4];
+    const int b = blockIdx.y, sc = blockIdx.z;
+    const int h = pyr.h[sc], w = pyr.w[sc], hw = h * w;
+    const float* d = pyr.disp[sc] + (size_t)b * hw;
+    const float* img = im.rgb0[sc] + (size_t)b * 3 * hw;
+    const float nx = 1.f / (float)(h * (w - 1)), ny = 1.f / (float)((h - 1) * w);
+    const int per = (hw + SI_CHUNKS - 1) / SI_CHUNKS;
+    const int p0 = blockIdx.x * per, p1 = min(hw, p0 + per);
+    float s = 0.f;
+    for (int p = p0 + (int)threadIdx.x; p < p1; p += 256) {
+        const int y = p / w, x = p - y * w;
+        if (x + 1 < w) s += fabsf(d[p] - d[p + 1]) * si_edge_weight(img, hw, p, p + 1) * nx;
+        if (y + 1 < h) s += fabsf(d[p] - d[p + w]) * si_edge_weight(img, hw, p, p + w) * ny;
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[((size_t)sc * B + b) * SI_CHUNKS + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// one thread: 4 x B terms, fixed order
+__global__ void smooth_intended_finalize_kernel(const float* __restrict__ partial, const float* __restrict__ means_all,
+                                                const float* __restrict__ sample_w, float* __restrict__ losses,
+                                                float* __restrict__ aux, int B, int H, int W, float smooth_scale) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float add_total = 0.f;
+    for (int s = 0; s < 4; ++s) {
+        const int hw = (H >> s) * (W >> s);
+        float sm = 0.f;
+        for (int b = 0; b < B; ++b) {
+            float m = 0.f, T = 0.f;
+            for (int k = 0; k < DM_CHUNKS; ++k) m += means_all[((size_t)s * B + b) * DM_CHUNKS + k];
+            for (int k = 0; k < SI_CHUNKS; ++k) T += partial[((size_t)s * B + b) * SI_CHUNKS + k];
+            const float inv = 1.f / (m / (float)hw + 1e-7f);
+            aux[((size_t)s * B + b) * 2 + 0] = inv;
+            aux[((size_t)s * B + b) * 2 + 1] = T;
+            sm += (inv * T) * sample_w[b];
+        }
+        const float reg = smooth_scale / (float)(1 << s) * sm;
+        losses[s * 4 + 1] = sm;
+        losses[s * 4 + 2] = reg;
+        losses[s * 4 + 3] += reg;
+        add_total += reg;
+    }
+    losses[17] += add_total / 4.f;
+}
+
+__global__ __launch_bounds__(256) void smooth_intended_bwd_kernel(Pyramid pyr, SiPtrs im, const float* __restrict__ aux,
+                                                                  const float* __restrict__ sample_w, SiDz out, int B,
+                                                                  float smooth_scale) {
+    const int b = blockIdx.y, sc = blockIdx.z;
+    const int h = pyr.h[sc], w = pyr.w[sc], hw = h * w;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= hw) return;
+    const float* d = pyr.disp[sc] + (size_t)b * hw;
+    const float* img = im.rgb0[sc] + (size_t)b * 3 * hw;
+    const float inv = aux[((size_t)sc * B + b) * 2 + 0], T = aux[((size_t)sc * B + b) * 2 + 1];
+    const float nx = 1.f / (float)(h * (w - 1)), ny = 1.f / (float)((h - 1) * w);
+    const int y = p / w, x = p - y * w;
+    const float dp = d[p];
+    auto sgn = [](float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); };
+    float g = 0.f;
+    if (x + 1 < w) g += sgn(dp - d[p + 1]) * si_edge_weight(img, hw, p, p + 1) * nx;
+    if (x >= 1) g -= sgn(d[p - 1] - dp) * si_edge_weight(img, hw, p - 1, p) * nx;
+    if (y + 1 < h) g += sgn(dp - d[p + w]) * si_edge_weight(img, hw, p, p + w) * ny;
+    if (y >= 1) g -= sgn(d[p - w] - dp) * si_edge_weight(img, hw, p - w, p) * ny;
+    const float coef = smooth_scale / (float)(1 << sc) / 4.f * sample_w[b];
+    const float dl = coef * (inv * g - T * inv * inv / (float)hw);
+    out.dz[sc][(size_t)b * hw + p] += dp * (1.f - dp) * dl;      // through the sigmoid of the disparity head
+}
+
+}  // namespace clslam
+
+extern "C" int clslam_smooth_intended_chunks() { return clslam::SI_CHUNKS; }
+
+extern "C" int clslam_smooth_intended_fwd(const float* const* disp, const float* const* rgb0, float* partial, int batch, int H, int W,
+                                          void* stream) {
+    CLSLAM_REQUIRE(disp && rgb0 && partial && (H >> 3) >= 2 && (W >> 3) >= 2, "smooth_intended_fwd: bad args");
+    if (!batch) return CLSLAM_OK;
+    clslam::SiPtrs im;
+    for (int s = 0; s < 4; ++s) im.rgb0[s] = rgb0[s];
+    hipLaunchKernelGGL(clslam::smooth_intended_fwd_kernel, dim3(clslam::SI_CHUNKS, batch, 4), dim3(256), 0, (hipStream_t)stream,
+                       make_pyramid(disp, H, W), im, partial, batch);
+    return check_launch("smooth_intended_fwd");
+}
+
+extern "C" int clslam_smooth_intended_finalize(const float* partial, const float* means, const float* sample_w, float* losses,
+                                               float* aux, int batch, int H, int W, float smooth_scale, void* stream) {
+    CLSLAM_REQUIRE(partial && means && sample_w && losses && aux, "smooth_intended_finalize: null");
+    if (!batch) return CLSLAM_OK;
+    hipLaunchKernelGGL(clslam::smooth_intended_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, partial, means, sample_w,
+                       losses, aux, batch, H, W, smooth_scale);
+    return check_launch("smooth_intended_finalize");
+}
+
+extern "C" int clslam_smooth_intended_bwd(const float* const* disp, const float* const* rgb0, const float* aux, const float* sample_w,
+                                          float* const* dz, int batch, int H, int W, float smooth_scale, void* stream) {
+    CLSLAM_REQUIRE(disp && rgb0 && aux && sample_w && dz, "smooth_intended_bwd: null");
+    if (!batch) return CLSLAM_OK;
+    clslam::SiPtrs im;
+    clslam::SiDz out;
+    for (int s = 0; s < 4; ++s) { im.rgb0[s] = rgb0[s]; out.dz[s] = dz[s]; }
+    hipLaunchKernelGGL(clslam::smooth_intended_bwd_kernel, dim3(clslam::cdiv(H * W, 256), batch, 4), dim3(256), 0, (hipStream_t)stream,
+                       make_pyramid(disp, H, W), im, aux, sample_w, out, batch, smooth_scale);
+    return check_launch("smooth_intended_bwd");
+}

@@ -99,7 +99,7 @@ class EngineAdam(optim.Adam):
 
 
 class DepthPosePrediction:
-    def __init__(self, dataset_config, config: Config, use_online: bool = False):
+    def __init__(self, dataset_config, config: Config, use_online: bool = False, reference_quirks: bool = True):
         # Initialize parameters (dpp.py:41-68) ===========
         self.config_file = config.config_file
         self.dataset_type = dataset_config.dataset
@@ -196,7 +196,8 @@ class DepthPosePrediction:
         self.online_models = {}
         self.engine = Engine(self.height, self.width, self.device, min_depth=self.min_depth, max_depth=self.max_depth,
                              disparity_smoothness=self.disparity_smoothness,
-                             velocity_loss_scaling=self.velocity_loss_scaling)
+                             velocity_loss_scaling=self.velocity_loss_scaling,
+                             reference_quirks=reference_quirks)   # False: opt-in per-sample smoothness
         for m in self.models.values():
             m.to(self.device)
         self.engine.bind(self.models)

@@ -215,6 +215,19 @@ int clslam_photo_automask_pyramid_rng(const float* warped, const float* target, 
                                       unsigned long long offset, unsigned char* sel, float* coef_sel, float* partial, int batch,
                                       int H, int W, void* stream);
 int clslam_tie_break_noise(float* out, size_t npix, unsigned long long seed, unsigned long long offset, void* stream);
+/* Opt-in "intended" smoothness (the per-sample edge-aware term of monodepth2 instead of the flattened-batch
+ * behaviour of dpp.py:1148-1176 that the default mode reproduces).  fwd: partial[4][B][clslam_smooth_intended_chunks()]
+ * sums of |d disp| * exp(-mean_c |d I|) / count over the x and y edges; finalize (after clslam_loss_finalize run with
+ * n_smooth = 0): adds sum_b w_b * inv_b * T_b per scale to losses[s*4+1..3] and losses[17], keeps aux[4][B][2] =
+ * (1/(mean disp + 1e-7), T); bwd: ADDS the term's gradient (through the mean normalisation and the head's sigmoid) to
+ * dz[s] (B,h_s,w_s).  means = the (4,B,clslam_disp_mean_chunks()) output of clslam_disp_mean_pyramid.               */
+int clslam_smooth_intended_chunks(void);
+int clslam_smooth_intended_fwd(const float* const* disp, const float* const* rgb0, float* partial, int batch, int H, int W,
+                               void* stream);
+int clslam_smooth_intended_finalize(const float* partial, const float* means, const float* sample_w, float* losses, float* aux,
+                                    int batch, int H, int W, float smooth_scale, void* stream);
+int clslam_smooth_intended_bwd(const float* const* disp, const float* const* rgb0, const float* aux, const float* sample_w,
+                               float* const* dz, int batch, int H, int W, float smooth_scale, void* stream);
 /* LDS-tiled fused loss backward on coef_sel; dp_partial [4][B][clslam_loss_bwd2_blocks][24].                */
 int clslam_loss_bwd2_blocks(int H, int W);
 int clslam_loss_bwd2_pyramid(const float* const* disp, const unsigned char* sel, const float* coef_sel, const float* warped,

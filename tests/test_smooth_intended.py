@@ -1,0 +1,50 @@
+"""Opt-in "intended" smoothness: DepthPosePrediction(..., reference_quirks=False) computes the per-sample
+edge-aware term of monodepth2 instead of the reference's flattened-batch behaviour (dpp.py:1148-1176).  Checked against the
+oracle's `smooth_loss_intended` branch: every loss scalar at 1e-4, the gradients of all trainable tensors as full tensors,
+and the term really differs from the default (parity) mode."""
+import math
+
+import pytest
+import torch
+
+from clslam_hip import synth
+from clslam_hip.engine import TrainableLayout
+from emu_util import BACKENDS, use_backend
+from helpers import make_oracle
+from predictor_util import make_predictor
+
+H, W, B = 64, 128, 2
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_intended_smoothness_matches_oracle(backend):
+    use_backend(backend)
+    batch = synth.make_batch(B, H, W, seed=7)
+    noise = synth.make_noise(B, H, W, seed=17)
+    # a smoothness weight large enough for the term to matter in the gradients (the shipped 1e-3 is ~1e-3 of the loss)
+    p = make_predictor(H, W, B, reference_quirks=False, disparity_smoothness=0.1)
+    o = make_oracle(H, W, B, reference_quirks=False, disparity_smoothness=0.1)
+    p.set_tie_break_noise(noise)
+    out, losses = p.adapt(None, {k: v.clone() for k, v in batch.items()}, steps=1)
+    o.set_adapt()
+    oo, ol = o.process_batch(batch, noise, None)
+    o.optimizer.zero_grad()
+    ol['loss'].backward()
+    for k, v in ol.items():
+        assert abs(float(losses[k]) - float(v.detach())) <= 1e-4 * max(abs(float(v.detach())), 1e-4), (k, float(losses[k]), float(v.detach()))
+    assert float(ol['reg_loss/scale_0'].detach()) > 0.01 * float(ol['loss'].detach())       # the term is not negligible here
+    eng = p.engine
+    eng.wait_training()
+    worst = 0.0
+    for name, off, shape in eng.layout.entries:
+        model, key = name.split('/', 1)
+        ref = dict(o.models[model].named_parameters())[key].grad
+        got = TrainableLayout.to_reference(eng.g[off:off + math.prod(shape)], shape).cpu()
+        err = float((got.double() - ref.double()).norm() / ref.double().norm().clamp_min(1e-30))
+        worst = max(worst, err)
+        assert err < 3e-2, (name, err)          # full tensors; the bound carries the photometric term's selection flips
+    # the default (parity) mode computes something else
+    q = make_predictor(H, W, B, disparity_smoothness=0.1)
+    q.set_tie_break_noise(noise)
+    _, lq = q.adapt(None, {k: v.clone() for k, v in batch.items()}, steps=1)
+    assert abs(float(lq['smooth_loss/scale_0']) - float(losses['smooth_loss/scale_0'])) > 1e-3 * abs(float(losses['smooth_loss/scale_0']))
