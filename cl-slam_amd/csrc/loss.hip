@@ -251,6 +251,16 @@ __global__ __launch_bounds__(256) void loss_bwd2_kernel(Pyramid pyr, const unsig
             if (y == H - 2) wy[2] = 2.f;
             if (x == 1) wx[0] = 2.f;
             if (x == W - 2) wx[2] = 2.f;
+            // Nothing to do for this frame where no pixel of the 3x3 neighbourhood selected it (the automask / the other
+            // frame won): the selection is spatially coherent, so whole waves (64 consecutive pixels of a row) skip the
+            // 81 coefficient reads, the projection and the gathers
+            bool any = false;
+#pragma unroll
+            for (int q = 0; q < 9; ++q) any |= ss[(ly + q / 3) * LB_PW + lx + q % 3] == want;
+            if (!any) {
+                if (fi == 0) ddisp_up[(size_t)b * HW + pi] = 0.f;
+                continue;
+            }
             float sA[3] = {0.f, 0.f, 0.f}, sB[3] = {0.f, 0.f, 0.f}, sC[3] = {0.f, 0.f, 0.f};
 #pragma unroll 1
             for (int dy = 0; dy < 3; ++dy)
