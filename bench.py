@@ -91,6 +91,10 @@ def cpu_baseline(H, W, B, budget_s=25.0):
     times.sort()
     med = times[len(times) // 2]
     return {'value': round(1.0 / med, 4), 'unit': 'frames/s', 'cores': best, 'kind': 'port',
+            # BASELINE.md section 3 asks for N = 8 threads and N = all hardware threads as well: single steps of the sweep
+            'frames_per_s_at_8_threads': round(1.0 / sweep[8], 4) if 8 in sweep else None,
+            'frames_per_s_at_all_threads': round(1.0 / sweep[default_threads], 4) if default_threads in sweep else None,
+            'all_threads': default_threads,
             'sample': f'{len(times)} adapt steps of the same B={B} {H}x{W} minibatch, torch {torch.__version__} CPU fp32, '
                       f'median {med:.3f} s/step at {best} threads (sweep s/step: '
                       + ', '.join(f'{n}: {t:.2f}' for n, t in sweep.items()) + ')'}

@@ -88,7 +88,7 @@ def main() -> None:
     assert shipped.loop_closure.id_threshold == 250 and shipped.depth_pose.batch_size == 3
 
     # --- a tiny synthetic run: same file, sizes/paths replaced -----------------------------------------------
-    make_kitti_tree(work / 'kitti', frames + 3, period=4)
+    make_kitti_tree(work / 'kitti', frames + 3, period=3)
     with open(REF / 'config' / 'config_adapt.yaml', encoding='utf-8') as f:
         cfg = yaml.safe_load(f)
     cfg['Dataset'].update(dataset_path=str(work / 'kitti'), height=H, width=W)

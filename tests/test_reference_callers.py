@@ -1,6 +1,6 @@
 """The drop-in boundary proved with the REFERENCE's own callers: with sys.path =
 [cl-slam_amd, /root/reference] -- INTEGRATION.md's recipe -- the reference's config/config_parser.py parses its
-own config_adapt.yaml, and its slam/slam.py (`Slam.__init__`, `Slam.step` x5, `Slam.save_model`),
+own config_adapt.yaml, and its slam/slam.py (`Slam.__init__`, `Slam.step` x4, `Slam.save_model`),
 datasets/kitti.py and slam/replay_buffer.py run UNCHANGED on the cl-slam_amd packages
 (depth_pose_prediction, loop_closure_detection, faiss).  Build container only (needs /root/reference; the HIP
 kernels run on the CPU emulator); tests/test_slam_usage.py::test_mini_slam_loop is the GPU twin."""
@@ -17,7 +17,7 @@ DRIVER = Path(__file__).parent / 'ref_callers_driver.py'
 
 @pytest.mark.skipif(not REF.exists(), reason='the reference checkout only exists in the build container')
 def test_reference_slam_runs_unchanged_on_the_product_packages(tmp_path):
-    r = subprocess.run([sys.executable, str(DRIVER), str(tmp_path), '5'], capture_output=True, text=True, timeout=1500)
+    r = subprocess.run([sys.executable, str(DRIVER), str(tmp_path), '4'], capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     line = next(ln for ln in r.stdout.splitlines() if ln.startswith('REPORT '))
     rep = json.loads(line[len('REPORT '):])
@@ -27,15 +27,15 @@ def test_reference_slam_runs_unchanged_on_the_product_packages(tmp_path):
     for name in ('depth_pose_prediction', 'loop_closure_detection', 'faiss'):
         assert '/cl-slam_amd/' in rep['origin'][name]
     steps = rep['steps']
-    assert [s['step'] for s in steps] == [1, 2, 3, 4, 5]
+    assert [s['step'] for s in steps] == [1, 2, 3, 4]
     for s in steps:
         assert 0 < s['loss'] < 10 and 0 <= s['velocity_loss'] < 1          # finite adaptation losses per frame
         assert s['lcd_frames'] == s['step'] and s['vertices'] == s['step'] + 1
         assert len(s['buffer']) <= 2                                          # max_buffer_size
-    # the synthetic camera returns to its start after 4 frames: frame 5 closes a loop with frame 1 (id gap > 2),
+    # the synthetic camera returns to its start after 3 frames: frame 4 closes a loop with frame 1 (id gap > 2),
     # which calls predict_pose and the (stubbed) graph optimisation
     assert steps[-1]['loop_closures'] == 1 and steps[-1]['optimize_calls'] == 1
-    assert rep['adam_steps'] == 5                                             # adaptation_epochs=1 x 5 frames
+    assert rep['adam_steps'] == 4                                             # adaptation_epochs=1 x 4 frames
     assert rep['saved'] == ['depth_decoder.pth', 'depth_encoder.pth', 'optimizer.pth', 'pose_decoder.pth', 'pose_encoder.pth']
     assert rep['buffer_state'] and rep['reloaded_ids'] == steps[-1]['buffer']
     assert len(rep['replay_files']) == len(steps[-1]['buffer'])
