@@ -297,7 +297,6 @@ class Engine:
         ws.P = E(2, B, 3, 4)
         ws.depth = E(4, B, H, W)
         ws.warped = E(4, 2, B, 3, H, W)
-        ws.idsrc = E(2, B, 3, H, W)
         ws.idmap = E(2, B, H, W)
         ws.coef = None  # allocated on the first training step
         ws.sel = torch.empty(4, B, H, W, dtype=torch.uint8, device=dev)
@@ -482,9 +481,9 @@ class Engine:
         def identity_and_noise() -> bool:
             """Identity reprojection maps (dpp.py:1047-1052) and the tie-break noise depend on the inputs only."""
             if not reuse:
-                ws.idsrc[0].copy_(rgb[-1])
-                ws.idsrc[1].copy_(rgb[1])
-                ops.photo_map(ws.idsrc, rgb[0], ws.idmap, None, 2 * B, B, H, W)
+                # one launch per source frame straight from the caller's planes (stacking them first cost two 7 MB copies)
+                ops.photo_map(rgb[-1], rgb[0], ws.idmap[0], None, B, B, H, W)
+                ops.photo_map(rgb[1], rgb[0], ws.idmap[1], None, B, B, H, W)
             if noise is not None:
                 for s in range(4):
                     ws.noise[s].copy_(noise[s])
