@@ -36,7 +36,7 @@ class DiversityBuffer:
         self._sim = torch.full((self.max_slots, self.max_slots), -1.0, device=self.device)
         self._occ = torch.zeros(self.max_slots, dtype=torch.uint8, device=self.device)
         self._scores = torch.empty(self.max_slots, device=self.device)
-        self._result = torch.empty(4, dtype=torch.int32, device=self.device)
+        self._result = torch.empty(5, dtype=torch.int32, device=self.device)
         self._simout = torch.empty(1, device=self.device)
         self._slot_ids = np.full(self.max_slots, -1, dtype=np.int64)   # distance_matrix_indices of the reference
         self.nslots = 0                               # slots ever used (high-water mark)
@@ -70,8 +70,9 @@ class DiversityBuffer:
         lib.call('clslam_diversity_commit', self._db.data_ptr(), self._sim.data_ptr(), self.max_slots, self._occ.data_ptr(),
                  self.nslots, self.max_slots, self.d, self.capacity, self.threshold, q.data_ptr(), self._scores.data_ptr(),
                  self._result.data_ptr(), self._simout.data_ptr(), stream)
-        accepted, slot, evict, _count = (int(v) for v in self._result.cpu())
-        similarity = float(self._simout.cpu())
+        res = self._result.cpu()                       # the one device->host copy of a candidate (20 bytes)
+        accepted, slot, evict, _count = (int(v) for v in res[:4])
+        similarity = float(res[4:5].view(torch.float32))
         if not accepted:
             return False, None, similarity
         self._slot_ids[slot] = int(sample_id)

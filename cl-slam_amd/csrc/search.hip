@@ -114,7 +114,8 @@ __global__ __launch_bounds__(256) void l2_normalize_kernel(float* __restrict__ x
 //      S[slot][slot] = <q,q>                                                (replay_buffer.py:112-139)
 //   3. more than `capacity` samples now: evict argmax_j (sum_i S[i][j] - S[j][j]), the sample most similar to
 //      all others (first maximum, column sums added in slot order like numpy's sum(0))   (replay_buffer.py:141-150)
-// result: [0]=accepted, [1]=slot written (-1), [2]=slot evicted (-1), [3]=occupied slots afterwards; sim_out[0].
+// result: [0]=accepted, [1]=slot written (-1), [2]=slot evicted (-1), [3]=occupied slots afterwards, [4]=the bits of the
+// nearest similarity (so that ONE 20-byte copy tells the host everything); sim_out[0] holds it as a float as well.
 __global__ __launch_bounds__(256) void diversity_commit_kernel(float* __restrict__ db, float* __restrict__ S, int ld,
                                                                unsigned char* __restrict__ occupied, int nslots, int max_slots,
                                                                int d, int capacity, float threshold,
@@ -156,6 +157,7 @@ __global__ __launch_bounds__(256) void diversity_commit_kernel(float* __restrict
         sh_slot = red_i[0] == INT_MAX ? nslots : red_i[0];
         sh_count = (int)red_v[0];
         sim_out[0] = similarity;
+        result[4] = __builtin_bit_cast(int, similarity);
     }
     __syncthreads();
     const int slot = sh_slot;

@@ -321,8 +321,8 @@ int clslam_l2_normalize_rows(float* x, int n, int d, void* stream);
  * = clslam_ip_scores(db, query) over the first nslots slots.  Accepts the candidate when its largest similarity to
  * an occupied slot is < threshold (0 for an empty buffer), writes it to the first free slot (or slot nslots) with
  * its row/column of sim, and when more than `capacity` slots are occupied evicts argmax_j(sum_i sim[i][j] -
- * sim[j][j]) (row/column set to -1, slot freed).  result[4] = {accepted, slot written, slot evicted, occupied
- * count}; similarity[0] = the nearest stored similarity.  One workgroup; no host decision between the steps. */
+ * sim[j][j]) (row/column set to -1, slot freed).  result[5] = {accepted, slot written, slot evicted, occupied
+ * count, bits of the nearest similarity}; similarity[0] = the nearest stored similarity as a float.  One workgroup; no host decision between the steps. */
 int clslam_diversity_commit(float* db, float* sim, int ld, unsigned char* occupied, int nslots, int max_slots, int d,
                             int capacity, float threshold, const float* query, const float* scores, int* result,
                             float* similarity, void* stream);
