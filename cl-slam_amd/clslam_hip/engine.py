@@ -365,9 +365,12 @@ class Engine:
             self._conv_ws[handle] = torch.zeros(self.CONV_WS_BYTES, dtype=torch.uint8, device=self.device)
             ops.set_conv_workspace(handle, self._conv_ws[handle])
 
-    def _encoder(self, e, bufs, n: int, stem_inputs) -> List[torch.Tensor]:
-        """stem_inputs: list of (img_a, img_b|None, batch offset, count); returns the 5 NHWC features."""
-        for img_a, img_b, off, cnt in stem_inputs:
+    def _encoder(self, e, bufs, n: int, stem_inputs, waits=None) -> List[torch.Tensor]:
+        """stem_inputs: list of (img_a, img_b|None, batch offset, count); returns the 5 NHWC features.
+        waits: one event per stem launch (its input image still crossing PCIe) for the current stream to wait on."""
+        for i, (img_a, img_b, off, cnt) in enumerate(stem_inputs):
+            if waits is not None:
+                torch.cuda.current_stream(self.device).wait_event(waits[i])
             ops.stem_conv(img_a, img_b, e.stem_w, e.stem_scale, e.stem_shift, bufs.f0[off:off + cnt])
         ops.maxpool3x3s2(bufs.f0, bufs.pool)
         x = bufs.pool
@@ -447,7 +450,7 @@ class Engine:
         H, W = self.H, self.W
         self._conv_workspace()
         if inputs_ready is not None:
-            # inputs still crossing PCIe on the caller's copy stream: events (rgb_aug[0] there, all rgb_aug there, everything
+            # inputs still crossing PCIe on the caller's copy stream: events (rgb_aug[0], rgb_aug[-1], rgb_aug[+1], everything
             # there).  The depth net only reads rgb_aug[0], the pose net the three rgb_aug frames; the un-augmented
             # frames are first needed by the identity maps / the loss stage.
             torch.cuda.current_stream(self.device).wait_event(inputs_ready[0])
@@ -504,7 +507,7 @@ class Engine:
             # the wgrad stream idles during the forward: the input-only work runs there, off the critical path
             wg.wait_stream(torch.cuda.current_stream(self.device))
             if inputs_ready is not None:
-                wg.wait_event(inputs_ready[2])
+                wg.wait_event(inputs_ready[3])
             with torch.cuda.stream(wg):
                 have_noise = identity_and_noise()
                 id_ready = torch.cuda.Event()
@@ -515,11 +518,10 @@ class Engine:
 
             def pose_branch():
                 with torch.cuda.stream(side):
-                    if inputs_ready is not None:
-                        side.wait_event(inputs_ready[1])
                     # pose pairs in temporal order (dpp.py:949-955): (-1, 0) and (0, +1), batched as 2B
                     pf4 = ws.pf4 if reuse else self._encoder(self.enc['pose_encoder'], ws.penc, 2 * B,
-                                                             [(aug[-1], aug[0], 0, B), (aug[0], aug[1], B, B)])[4]
+                                                             [(aug[-1], aug[0], 0, B), (aug[0], aug[1], B, B)],
+                                                             waits=None if inputs_ready is None else inputs_ready[1:3])[4]
                     self.wait_training(side)      # the (frozen) encoder above does not need the optimizer step in flight
                     self._pose_decoder(ws, pf4)
                     return pf4
@@ -548,15 +550,14 @@ class Engine:
             self.wait_training()
             dfeats = ws.dfeats if reuse else self._encoder(self.enc['depth_encoder'], ws.denc, B, [(aug[0], None, 0, B)])
             self._depth_decoder(ws, dfeats)
-            if inputs_ready is not None:
-                torch.cuda.current_stream(self.device).wait_event(inputs_ready[1])
             pf4 = ws.pf4 if reuse else self._encoder(self.enc['pose_encoder'], ws.penc, 2 * B,
-                                                     [(aug[-1], aug[0], 0, B), (aug[0], aug[1], B, B)])[4]
+                                                     [(aug[-1], aug[0], 0, B), (aug[0], aug[1], B, B)],
+                                                     waits=None if inputs_ready is None else inputs_ready[1:3])[4]
             self._pose_decoder(ws, pf4)
         ws.dfeats, ws.pf4 = dfeats, pf4
         # view synthesis + loss ------------------------------------------------------------------
         if inputs_ready is not None:
-            torch.cuda.current_stream(self.device).wait_event(inputs_ready[2])
+            torch.cuda.current_stream(self.device).wait_event(inputs_ready[3])
         K = self._mat(inputs['camera_matrix', 0])
         Kinv = self._mat(inputs['inv_camera_matrix', 0])
         ops.pose_to_proj(ws.pose, K, ws.T, ws.P)

@@ -525,8 +525,8 @@ class DepthPosePrediction:
         """Move the caller's dict to the device in place like dpp.py:916-917 -- but only the 13 entries the path reads
         (9 image planes of 24; CLSLAM_UPLOAD_ALL=1 / upload_all_inputs moves every entry like the reference), and
         asynchronously: the copies run on their own stream (pinned sources: DataLoader(pin_memory=True), slam.py:86),
-        the three network inputs first.  Returns the events (depth-net input there, pose-net inputs there, everything
-        there) for the engine's streams to wait on, or None when nothing had to move."""
+        the three network inputs first.  Returns the events (rgb_aug[0] there, rgb_aug[-1] there, rgb_aug[+1] there,
+        everything there) for the engine's streams to wait on, or None when nothing had to move."""
         dev = self.device
         todo = [k for k in self.UPLOAD_FIRST + self.UPLOAD_REST if k in inputs and inputs[k].device != dev]
         extra = [k for k in inputs if self.upload_all_inputs and k not in self.UPLOAD_FIRST + self.UPLOAD_REST
@@ -550,10 +550,9 @@ class DepthPosePrediction:
             inputs[k] = t
         with torch.cuda.stream(cs):
             evs = []
-            for group in ([self.UPLOAD_FIRST[0]], self.UPLOAD_FIRST[1:]):   # depth-net input, then the pose pairs' frames
-                for k in group:
-                    if k in todo:
-                        copy(k)
+            for k in self.UPLOAD_FIRST:      # rgb_aug[0] (depth net, first pose pair), rgb_aug[-1] (first pair), rgb_aug[+1] (second pair)
+                if k in todo:
+                    copy(k)
                 ev = torch.cuda.Event()
                 ev.record(cs)
                 evs.append(ev)
@@ -562,7 +561,7 @@ class DepthPosePrediction:
                     copy(k)
             all_ev = torch.cuda.Event()
             all_ev.record(cs)
-        return evs[0], evs[1], all_ev
+        return evs[0], evs[1], evs[2], all_ev
 
     def _process_batch(self, inputs: Dict[Any, Tensor], loss_sample_weights: Optional[Tensor] = None,
                        use_online: bool = False, train: bool = False, graphed: bool = False, copy_inputs: bool = True,
@@ -574,7 +573,7 @@ class DepthPosePrediction:
         sample_w, smooth_w = self._sample_weights(B, loss_sample_weights, local=not train)
         if graphed:
             if ready is not None:
-                torch.cuda.current_stream(self.device).wait_event(ready[2])
+                torch.cuda.current_stream(self.device).wait_event(ready[3])
             outputs, losses = self.engine.train_step_graphed(inputs, sample_w=sample_w, smooth_w=smooth_w,
                                                              noise=self._injected_noise, copy_inputs=copy_inputs,
                                                              reuse_frozen=reuse_frozen, want_outputs=want_outputs)
