@@ -202,3 +202,31 @@ def test_uniform_random_image_content_matches_oracle(backend):
         assert rel_err(out['rgb', -1, s].cpu(), oo['rgb', -1, s].detach()) < 2e-3
     for k, v in ol.items():
         assert abs(float(losses[k]) - float(v)) <= 1e-4 * max(abs(float(v)), 1e-3), k
+
+
+@pytest.mark.gpu
+def test_host_batch_upload_is_selective_asynchronous_and_invisible():
+    """adapt() on a pinned HOST minibatch (slam.py hands over DataLoader output): only the 13 entries the path reads are
+    moved to the device (dpp.py:916-917 moves all 35), on a copy stream with the network inputs first -- and the step is
+    bitwise the one computed from a minibatch already resident in HBM; the loss dict comes back on the host."""
+    use_backend('hip')
+    B = 3
+    batch = synth.make_batch(B, H, W, seed=51)
+    noise = {s: v.cuda() for s, v in synth.make_noise(B, H, W, seed=52).items()}
+    results = []
+    for mode in ('device', 'host'):
+        p = make_predictor(H, W, B)
+        p.set_tie_break_noise(noise)
+        feed = {k: (v.cuda() if mode == 'device' else v.clone().pin_memory()) for k, v in batch.items()}
+        for _ in range(2):                       # twice: the second call re-uploads into recycled blocks
+            moved = dict(feed) if mode == 'host' else feed
+            out, losses = p.adapt(None, moved, steps=1)
+        torch.cuda.synchronize()
+        if mode == 'host':
+            on_dev = sorted(str(k) for k, v in moved.items() if v.is_cuda)
+            assert len(on_dev) == 13 and all(k in moved and moved[k].is_cuda for k in p.UPLOAD_FIRST + p.UPLOAD_REST)
+            assert not moved['rgb', -1, 2].is_cuda and not moved['rgb_aug', 0, 3].is_cuda      # never read: left alone
+        assert all(not v.is_cuda for v in losses.values())                                     # one D2H per step
+        results.append((out['depth', 0].clone(), out['cam_T_cam', 0, 1].clone(), float(losses['loss']), p.engine.w.clone()))
+    for a, b in zip(results[0], results[1]):
+        assert (a == b) if isinstance(a, float) else torch.equal(a, b)
