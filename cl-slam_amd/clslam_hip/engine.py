@@ -652,7 +652,10 @@ class Engine:
         plan = t.plan.get(name_prefix)
         if plan is None:
             use_patch = ops.wgrad_patch_supported(desc)
-            splits = ops.wgrad_patch_splits(desc, 512) if use_patch else ops.wgrad_splits(desc, 512)
+            # two blocks per CU: 256 / 128 blocks would halve / quarter the 220 MB of split partials but measured 3.38 / 3.44 ms
+            # per step against 3.34 (the wgrad launches become the tail of the backward)
+            tb = int(os.environ.get('CLSLAM_WGRAD_BLOCKS', '512'))
+            splits = ops.wgrad_patch_splits(desc, tb) if use_patch else ops.wgrad_splits(desc, tb)
             plan = SimpleNamespace(use_patch=use_patch, splits=splits, partial=torch.empty(splits * n, device=self.device),
                                    colsum=None, nb=0)
             t.items.append((plan.partial, self._slot(self.g, name_prefix + '.weight', n), n, splits))

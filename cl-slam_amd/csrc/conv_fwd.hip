@@ -259,13 +259,20 @@ extern "C" int clslam_conv2d_pick_config(const clslam_conv_desc* d) {
                        d->config != -2;          // config -2: the tiled kernels only (fallback of clslam_conv2d below)
     static const int sk_all = getenv("CLSLAM_SK_ALL") ? atoi(getenv("CLSLAM_SK_ALL")) : 0;   // experiment knob
     if (sk_ok && sk_all && Cin >= sk_all) return d->stride == 2 ? (d->out_w <= 44 ? 31 : 30) : (d->out_w <= 44 ? 32 : 30);
-    // (a tile shared by more than ~8 workgroups makes its owner gather that many slabs one after the other: with fewer
-    // than 32 tiles of 128 px x 64 ch -- the B = 1 minibatch on the 6x20 layers -- the tiled kernel is the faster one)
+    // Measured per layer shape at B = 5 and B = 1 (tools/bench_conv.py, profiles/r02c_conv_microbench*.txt).  The choice
+    // between 128- and 64-pixel tiles is the number of (tile, chunk) units: fewer than five per workgroup and the smaller
+    // tile's finer cut wins.  Stand-alone the even split also wins on the small minibatches since the owner of a tile fetches
+    // its contributors' slabs four at a time (B = 1: 14.6 -> 34.5 TFLOP/s on layer4) -- but a stream-K launch holds every
+    // CU (two 220-VGPR waves per SIMD, 120 KB of LDS), so the other two streams of a step stand still behind it: inside
+    // the step the B = 1 / B = 3 minibatches measured 1.60-1.76 / 2.39 ms with it against 1.55 / 2.33 ms without.  Hence the
+    // fill rule: stream-K only where a launch has 32+ tiles of 128 px x 64 ch to cut.
     const bool sk_fill = (long long)d->batch * cdiv(d->out_h * d->out_w, 128) * cdiv(d->ch_out, 64) >= 32;
     if (sk_ok && sk_fill && d->stride == 1 && d->out_h == d->in_h + 2 * d->pad - 2 && d->out_w == d->in_w + 2 * d->pad - 2) {
-        if (d->out_w <= 24 && Cin >= 256) return d->ch_out >= 512 ? 32 : 33;
-        if (d->out_w <= 44 && (Cin >= 512 || (Cin >= 256 && M >= 4000))) return 32;
-        if (d->out_w <= 84 && d->out_w > 44 && Cin >= 256) return 30;
+        const long long units128 = (long long)d->batch * cdiv(d->out_h * d->out_w, 128) * cdiv(d->ch_out, 64) * (Cin / 16);
+        // 256 -> 256 @12x40 at B = 5 is a tie stand-alone (74.0 tiled / 73.6) and 0.5 % slower inside the step: tiled
+        const bool tie_case = Cin < 512 && d->ch_out >= 256 && d->out_w > 24 && units128 >= 1280 && M < 4000;
+        if (d->out_w <= 44 && Cin >= 256 && !tie_case) return units128 >= 1280 ? 32 : 33;
+        if (d->out_w <= 84 && d->out_w > 44 && Cin >= 256 && M >= 4000) return 30;
     }
     if (sk_ok && sk_fill && d->stride == 2 && d->out_w <= 24 && Cin >= 256) return 30;
     if (d->ksize == 3 && d->stride == 1 && d->out_h == d->in_h + 2 * d->pad - 2 && d->out_w == d->in_w + 2 * d->pad - 2) {

@@ -83,6 +83,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void conv3x3_sk_kernel(SkK p) {
 #endif
     const long long u0 = (long long)grp * p.units / p.G, u1 = (long long)(grp + 1) * p.units / p.G;
     if (u0 >= u1) return;
+    if (tid == 0) s_flag_ok = 1;                                // cleared by a hand-off that timed out (finish)
 
     // ---- lane constants of the DMA: row inside a piece, swizzled source slot --------------------------------
     const int drow = lane >> 2;
@@ -254,33 +255,45 @@ __global__ __launch_bounds__(NWM * NWN * 64) void conv3x3_sk_kernel(SkK p) {
             return;
         }
         if (c_lo > 0) {
-            // the head of this tile was computed by the preceding ranges (possibly several): add their slabs,
-            // nearest range first -- a fixed order for a given launch geometry
+            // the head of this tile was computed by the preceding ranges (possibly several): add their slabs, nearest
+            // range first -- a fixed order for a given launch geometry.  All their flags are polled at once (one lane
+            // each) and the slabs are fetched four at a time: one memory round trip per four contributors instead of
+            // two per contributor (flag, then slab) -- the owners reach this point together, at the end of the launch.
             const long long tile_first = (long long)t * p.NC;
-            for (int g2 = grp - 1; g2 >= 0 && (long long)(g2 + 1) * p.units / p.G > tile_first; --g2) {
-                if (tid == 0) {
-                    unsigned spins = 0;
-                    while (coherent_load_u32(&p.flags[g2]) == 0u && ++spins < kSkSpinLimit) spin_pause();
-                    s_flag_ok = spins < kSkSpinLimit;
-                    uncounted_flag_store(&p.flags[g2], 0u);       // zero again for the next launch on this stream
-                }
-                __syncthreads();
-                const float* slab = p.slabs + (size_t)g2 * (BM * BN) + (size_t)wave * (TM * TN * 256) + lane * 4;
-                const float poison = s_flag_ok ? 0.f : __builtin_nanf("");   // a lost hand-off must not pass silently
-                f32x4 part[TM * TN];
-                if constexpr (TM * TN == 4) coherent_load4x4(slab, part[0], part[1], part[2], part[3]);
-                else if constexpr (TM * TN == 2) coherent_load4x2(slab, part[0], part[1]);
+            int ncon = 0;
+            for (int g2 = grp - 1; g2 >= 0 && (long long)(g2 + 1) * p.units / p.G > tile_first; --g2) ++ncon;
+            for (int q = tid; q < ncon; q += NT) {
+                unsigned spins = 0;
+                while (coherent_load_u32(&p.flags[grp - 1 - q]) == 0u && ++spins < kSkSpinLimit) spin_pause();
+                if (spins >= kSkSpinLimit) s_flag_ok = 0;
+                uncounted_flag_store(&p.flags[grp - 1 - q], 0u);   // zero again for the next launch on this stream
+            }
+            __syncthreads();
+            const float poison = s_flag_ok ? 0.f : __builtin_nanf("");   // a lost hand-off must not pass silently
+            const float* slab0 = p.slabs + (size_t)wave * (TM * TN * 256) + lane * 4;
+            for (int base = 0; base < ncon; base += 4) {
+                const float* sp[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) sp[q] = slab0 + (size_t)(grp - 1 - min(base + q, ncon - 1)) * (BM * BN);
+                f32x4 part[4][TM * TN];
+                if constexpr (TM * TN == 4) coherent_load4x4_x4(sp[0], sp[1], sp[2], sp[3], part[0], part[1], part[2], part[3]);
+                else if constexpr (TM * TN == 2) coherent_load4x2_x4(sp[0], sp[1], sp[2], sp[3], part[0], part[1], part[2], part[3]);
                 else {
 #pragma unroll
-                    for (int q = 0; q < TM * TN; q += 2) coherent_load4x2(slab + q * 256, part[q], part[q + 1]);
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int r = 0; r < TM * TN; r += 2) coherent_load4x2(sp[q] + r * 256, part[q][r], part[q][r + 1]);
                 }
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
+                for (int q = 0; q < 4; ++q)
+                    if (base + q < ncon) {
 #pragma unroll
-                    for (int j = 0; j < TN; ++j)
+                        for (int i = 0; i < TM; ++i)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) acc[i][j][r] += part[i * TN + j][r] + poison;
-                __syncthreads();
+                            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) acc[i][j][r] += part[q][i * TN + j][r] + poison;
+                    }
             }
         }
         if (p.dbg & 1) { if (acc[0][0][0] == 12345.678f) uncounted_flag_store((unsigned*)p.out, 1u); return; }

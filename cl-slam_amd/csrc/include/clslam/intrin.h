@@ -130,6 +130,42 @@ __device__ __forceinline__ void coherent_load4x2(const float* p, f32x4& a, f32x4
                  "s_waitcnt vmcnt(0)"
                  : "=&v"(a), "=&v"(b) : "v"(p) : "memory");
 }
+// The same rows of FOUR slabs in one round trip (the owner of a tile gathers its contributors four at a time).
+__device__ __forceinline__ void coherent_load4x4_x4(const float* p0, const float* p1, const float* p2, const float* p3,
+                                                    f32x4 (&a)[4], f32x4 (&b)[4], f32x4 (&c)[4], f32x4 (&d)[4]) {
+#ifdef CLSLAM_SCALAR_HANDOFF
+    coherent_load4x4(p0, a[0], a[1], a[2], a[3]); coherent_load4x4(p1, b[0], b[1], b[2], b[3]);
+    coherent_load4x4(p2, c[0], c[1], c[2], c[3]); coherent_load4x4(p3, d[0], d[1], d[2], d[3]);
+    return;
+#endif
+    asm volatile("global_load_dwordx4 %0, %16, off sc0 sc1\n\tglobal_load_dwordx4 %1, %16, off offset:1024 sc0 sc1\n\t"
+                 "global_load_dwordx4 %2, %16, off offset:2048 sc0 sc1\n\tglobal_load_dwordx4 %3, %16, off offset:3072 sc0 sc1\n\t"
+                 "global_load_dwordx4 %4, %17, off sc0 sc1\n\tglobal_load_dwordx4 %5, %17, off offset:1024 sc0 sc1\n\t"
+                 "global_load_dwordx4 %6, %17, off offset:2048 sc0 sc1\n\tglobal_load_dwordx4 %7, %17, off offset:3072 sc0 sc1\n\t"
+                 "global_load_dwordx4 %8, %18, off sc0 sc1\n\tglobal_load_dwordx4 %9, %18, off offset:1024 sc0 sc1\n\t"
+                 "global_load_dwordx4 %10, %18, off offset:2048 sc0 sc1\n\tglobal_load_dwordx4 %11, %18, off offset:3072 sc0 sc1\n\t"
+                 "global_load_dwordx4 %12, %19, off sc0 sc1\n\tglobal_load_dwordx4 %13, %19, off offset:1024 sc0 sc1\n\t"
+                 "global_load_dwordx4 %14, %19, off offset:2048 sc0 sc1\n\tglobal_load_dwordx4 %15, %19, off offset:3072 sc0 sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(a[3]), "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]), "=&v"(b[3]),
+                   "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2]), "=&v"(c[3]), "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3])
+                 : "v"(p0), "v"(p1), "v"(p2), "v"(p3) : "memory");
+}
+__device__ __forceinline__ void coherent_load4x2_x4(const float* p0, const float* p1, const float* p2, const float* p3,
+                                                    f32x4 (&a)[2], f32x4 (&b)[2], f32x4 (&c)[2], f32x4 (&d)[2]) {
+#ifdef CLSLAM_SCALAR_HANDOFF
+    coherent_load4x2(p0, a[0], a[1]); coherent_load4x2(p1, b[0], b[1]);
+    coherent_load4x2(p2, c[0], c[1]); coherent_load4x2(p3, d[0], d[1]);
+    return;
+#endif
+    asm volatile("global_load_dwordx4 %0, %8, off sc0 sc1\n\tglobal_load_dwordx4 %1, %8, off offset:1024 sc0 sc1\n\t"
+                 "global_load_dwordx4 %2, %9, off sc0 sc1\n\tglobal_load_dwordx4 %3, %9, off offset:1024 sc0 sc1\n\t"
+                 "global_load_dwordx4 %4, %10, off sc0 sc1\n\tglobal_load_dwordx4 %5, %10, off offset:1024 sc0 sc1\n\t"
+                 "global_load_dwordx4 %6, %11, off sc0 sc1\n\tglobal_load_dwordx4 %7, %11, off offset:1024 sc0 sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(a[0]), "=&v"(a[1]), "=&v"(b[0]), "=&v"(b[1]), "=&v"(c[0]), "=&v"(c[1]), "=&v"(d[0]), "=&v"(d[1])
+                 : "v"(p0), "v"(p1), "v"(p2), "v"(p3) : "memory");
+}
 // nothing is scheduled across this point (pins the fragment reads of the next tap ahead of the current tap's MFMAs)
 __device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 // vmcnt(0) THROUGH THE BUILTIN: unlike the asm form hipcc's wait-count pass sees it and knows that none of ITS

@@ -88,6 +88,16 @@ inline void coherent_load4x2(const float* p, f32x4& a, f32x4& b) {
     __atomic_thread_fence(__ATOMIC_SEQ_CST);
     memcpy(&a, p, 16); memcpy(&b, p + 256, 16);
 }
+inline void coherent_load4x4_x4(const float* p0, const float* p1, const float* p2, const float* p3,
+                                f32x4 (&a)[4], f32x4 (&b)[4], f32x4 (&c)[4], f32x4 (&d)[4]) {
+    coherent_load4x4(p0, a[0], a[1], a[2], a[3]); coherent_load4x4(p1, b[0], b[1], b[2], b[3]);
+    coherent_load4x4(p2, c[0], c[1], c[2], c[3]); coherent_load4x4(p3, d[0], d[1], d[2], d[3]);
+}
+inline void coherent_load4x2_x4(const float* p0, const float* p1, const float* p2, const float* p3,
+                                f32x4 (&a)[2], f32x4 (&b)[2], f32x4 (&c)[2], f32x4 (&d)[2]) {
+    coherent_load4x2(p0, a[0], a[1]); coherent_load4x2(p1, b[0], b[1]);
+    coherent_load4x2(p2, c[0], c[1]); coherent_load4x2(p3, d[0], d[1]);
+}
 inline void wg_barrier_keep_dma() { emu_sync_block(); }
 
 inline float wave_shfl_xor(float v, int mask) {
