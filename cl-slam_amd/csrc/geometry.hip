@@ -60,58 +60,63 @@ __global__ void pose_to_proj_kernel(const float* __restrict__ pose, const float*
 
 // ------------------------------------------------------------------------------------------------
 // depth[s,b,y,x] and warped[s,fi,b,c,y,x] for the pyr.n scales of a pyramid (one launch).
+// The kernel is VALU-bound, not HBM-bound (94 MB per launch at B = 5): its first version spent ~880 issue slots per pixel,
+// a third of them on index arithmetic (a flat index split by runtime divisors, 64-bit address chains, quarter-rate 32-bit
+// multiplies).  Now a block owns a 4 x 64 pixel tile of one (sample, scale): the tile origin is scalar, every address is a
+// uniform base pointer plus one unsigned 32-bit offset (saddr + voffset form) and products are 24-bit (full rate).  The
+// floating-point expressions are unchanged.
+constexpr int WF_TH = 4, WF_TW = 64;
 __global__ __launch_bounds__(256) void warp_fwd_kernel(Pyramid pyr, const float* __restrict__ src_m1,
                                                        const float* __restrict__ src_p1, const float* __restrict__ Kinv,
                                                        const float* __restrict__ P, float* __restrict__ depth_all,
                                                        float* __restrict__ warped_all, int B, int H, int W, float da, float db,
-                                                       int dmode) {
-    // 32-bit indexing (the host checks 4*B*H*W < 2^31).  The 12 bilinear taps of a frame are loaded
-    // unconditionally from clamped addresses and out-of-image taps get weight 0 (adding 0 leaves the sum
-    // bit-identical): with `if (x1ok) v += pl[..]` every tap was a branch + a load + a wait.
-    const int per = B * H * W;
-    const int total = per * pyr.n;
-    for (int gidx = blockIdx.x * 256 + threadIdx.x; gidx < total; gidx += gridDim.x * 256) {
-        const int sc = gidx / per;
-        const int idx = gidx - sc * per;
-        const int h = pyr.h[sc], w = pyr.w[sc];
-        float* depth = depth_all + (size_t)sc * per;
-        float* warped = warped_all + (size_t)sc * per * 6;
-        const int x = idx % W, row = idx / W, y = row % H, b = row / H;
-        const float disp = upsample_disp(pyr.disp[sc] + (size_t)b * h * w, h, w, H, W, y, x);
-        const float dep = disp_to_depth_dev(disp, da, db, dmode);
-        depth[idx] = dep;
-        const float* Ki = Kinv + (size_t)b * 16;
-        const float fx = (float)x, fy = (float)y;
-        float X[3];
-        for (int i = 0; i < 3; ++i) X[i] = dep * (Ki[i * 4 + 0] * fx + Ki[i * 4 + 1] * fy + Ki[i * 4 + 2]);
+                                                       int dmode, int tilesX) {
+    const int b = blockIdx.y, sc = blockIdx.z;
+    const int ty = blockIdx.x / tilesX, tx = blockIdx.x - ty * tilesX;
+    const int x = tx * WF_TW + (int)(threadIdx.x & 63), y = ty * WF_TH + (int)(threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    const unsigned HW = (unsigned)(H * W);
+    const unsigned pix = __umul24((unsigned)y, (unsigned)W) + (unsigned)x;
+    const int h = pyr.h[sc], w = pyr.w[sc];
+    const float disp = upsample_disp(pyr.disp[sc] + (size_t)b * h * w, h, w, H, W, y, x);
+    const float dep = disp_to_depth_dev(disp, da, db, dmode);
+    (depth_all + ((size_t)sc * B + b) * HW)[pix] = dep;
+    const float* Ki = Kinv + (size_t)b * 16;
+    const float fx = (float)x, fy = (float)y;
+    float X[3];
+    for (int i = 0; i < 3; ++i) X[i] = dep * (Ki[i * 4 + 0] * fx + Ki[i * 4 + 1] * fy + Ki[i * 4 + 2]);
+    // The 12 bilinear taps of a frame are loaded unconditionally from clamped addresses and out-of-image taps get weight 0
+    // (adding 0 leaves the sum bit-identical): with `if (x1ok) v += pl[..]` every tap was a branch + a load + a wait.
 #pragma unroll
-        for (int fi = 0; fi < 2; ++fi) {
-            const float* Pm = P + ((size_t)fi * B + b) * 12;
-            float p[3];
-            for (int i = 0; i < 3; ++i) p[i] = Pm[i * 4 + 0] * X[0] + Pm[i * 4 + 1] * X[1] + Pm[i * 4 + 2] * X[2] + Pm[i * 4 + 3];
-            const float den = p[2] + 1e-7f;
-            const Sample s = sample_coords(p[0] / den, p[1] / den, H, W);
-            const float wx1 = s.ix - (float)s.x0, wy1 = s.iy - (float)s.y0;
-            const float wx0 = (float)(s.x0 + 1) - s.ix, wy0 = (float)(s.y0 + 1) - s.iy;
-            const bool x1ok = s.x0 + 1 < W, y1ok = s.y0 + 1 < H;
-            const int x1 = x1ok ? s.x0 + 1 : s.x0, y1 = y1ok ? s.y0 + 1 : s.y0;
-            const float w00 = wx0 * wy0, w10 = wx1 * wy0, w01 = wx0 * wy1, w11 = wx1 * wy1;
-            const float* src = (fi == 0 ? src_m1 : src_p1) + (size_t)b * 3 * H * W;
-            float nw[3], ne[3], sw[3], se[3];
+    for (int fi = 0; fi < 2; ++fi) {
+        const float* Pm = P + ((size_t)fi * B + b) * 12;
+        float p[3];
+        for (int i = 0; i < 3; ++i) p[i] = Pm[i * 4 + 0] * X[0] + Pm[i * 4 + 1] * X[1] + Pm[i * 4 + 2] * X[2] + Pm[i * 4 + 3];
+        const float den = p[2] + 1e-7f;
+        const Sample s = sample_coords(p[0] / den, p[1] / den, H, W);
+        const float wx1 = s.ix - (float)s.x0, wy1 = s.iy - (float)s.y0;
+        const float wx0 = (float)(s.x0 + 1) - s.ix, wy0 = (float)(s.y0 + 1) - s.iy;
+        const bool x1ok = s.x0 + 1 < W, y1ok = s.y0 + 1 < H;
+        const float w00 = wx0 * wy0, w10 = wx1 * wy0, w01 = wx0 * wy1, w11 = wx1 * wy1;
+        const unsigned o00 = __umul24((unsigned)s.y0, (unsigned)W) + (unsigned)s.x0;
+        const unsigned o10 = o00 + (x1ok ? 1u : 0u);
+        const unsigned o01 = o00 + (y1ok ? (unsigned)W : 0u);
+        const unsigned o11 = o01 + (x1ok ? 1u : 0u);
+        const float* src = (fi == 0 ? src_m1 : src_p1) + (size_t)b * 3 * HW;
+        float* wout = warped_all + (((size_t)sc * 2 + fi) * B + b) * 3 * HW;
+        float nw[3], ne[3], sw[3], se[3];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const float* pl = src + (size_t)c * H * W;
-                nw[c] = pl[s.y0 * W + s.x0]; ne[c] = pl[s.y0 * W + x1];
-                sw[c] = pl[y1 * W + s.x0]; se[c] = pl[y1 * W + x1];
-            }
+        for (int c = 0; c < 3; ++c) {
+            const float* pl = src + (size_t)c * HW;
+            nw[c] = pl[o00]; ne[c] = pl[o10]; sw[c] = pl[o01]; se[c] = pl[o11];
+        }
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                float v = nw[c] * w00;
-                if (x1ok) v += ne[c] * w10;
-                if (y1ok) v += sw[c] * w01;
-                if (x1ok && y1ok) v += se[c] * w11;
-                warped[(((size_t)fi * B + b) * 3 + c) * H * W + (size_t)y * W + x] = v;
-            }
+        for (int c = 0; c < 3; ++c) {
+            float v = nw[c] * w00;
+            if (x1ok) v += ne[c] * w10;
+            if (y1ok) v += sw[c] * w01;
+            if (x1ok && y1ok) v += se[c] * w11;
+            (wout + (size_t)c * HW)[pix] = v;
         }
     }
 }
@@ -322,8 +327,9 @@ extern "C" int clslam_warp_fwd(const float* disp_s, int h, int w, const float* s
     Pyramid pyr;
     pyr.n = 1; pyr.disp[0] = disp_s; pyr.h[0] = h; pyr.w[0] = w;
     for (int k = 1; k < 4; ++k) { pyr.disp[k] = nullptr; pyr.h[k] = pyr.w[k] = 0; }
-    hipLaunchKernelGGL(warp_fwd_kernel, dim3((unsigned)std::min<size_t>(8192, (total + 255) / 256)), dim3(256), 0,
-                       (hipStream_t)stream, pyr, src_m1, src_p1, inv_k, proj, depth, warped, batch, H, W, a, b, mode);
+    const int tilesX = cdiv(W, WF_TW);
+    hipLaunchKernelGGL(warp_fwd_kernel, dim3(tilesX * cdiv(H, WF_TH), batch, 1), dim3(256), 0,
+                       (hipStream_t)stream, pyr, src_m1, src_p1, inv_k, proj, depth, warped, batch, H, W, a, b, mode, tilesX);
     return check_launch("warp_fwd");
 }
 
@@ -341,8 +347,9 @@ extern "C" int clslam_warp_fwd_pyramid(const float* const* disp, const float* sr
     const size_t total = (size_t)4 * batch * H * W;
     if (!total) return CLSLAM_OK;
     CLSLAM_REQUIRE(total < ((size_t)1 << 31), "warp_fwd_pyramid: batch too large for 32-bit indexing");
-    hipLaunchKernelGGL(warp_fwd_kernel, dim3((unsigned)std::min<size_t>(16384, (total + 255) / 256)), dim3(256), 0,
-                       (hipStream_t)stream, pyr, src_m1, src_p1, inv_k, proj, depth, warped, batch, H, W, a, b, mode);
+    const int tilesX = cdiv(W, WF_TW);
+    hipLaunchKernelGGL(warp_fwd_kernel, dim3(tilesX * cdiv(H, WF_TH), batch, 4), dim3(256), 0,
+                       (hipStream_t)stream, pyr, src_m1, src_p1, inv_k, proj, depth, warped, batch, H, W, a, b, mode, tilesX);
     return check_launch("warp_fwd_pyramid");
 }
 

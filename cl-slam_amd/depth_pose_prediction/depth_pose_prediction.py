@@ -99,7 +99,8 @@ class EngineAdam(optim.Adam):
 
 
 class DepthPosePrediction:
-    def __init__(self, dataset_config, config: Config, use_online: bool = False, reference_quirks: bool = True):
+    def __init__(self, dataset_config, config: Config, use_online: bool = False, reference_quirks: bool = True,
+                 host_pose_output: Optional[bool] = None):
         # Initialize parameters (dpp.py:41-68) ===========
         self.config_file = config.config_file
         self.dataset_type = dataset_config.dataset
@@ -228,6 +229,17 @@ class DepthPosePrediction:
         # network inputs first -- the encoders start while the loss-stage images are still crossing PCIe
         self.upload_all_inputs = os.environ.get('CLSLAM_UPLOAD_ALL', '0') == '1'
         self._copy_stream = None
+        # adapt(online, training) hands out outputs['cam_T_cam', 0, +-1] as HOST tensors (staged with the loss scalars behind
+        # the forward, before the backward is enqueued).  The caller reads exactly these back after every frame
+        # (slam.py:181-186: `[0, :]`, linalg.inv, `.cpu()`): on device tensors that `.cpu()` is ordered behind the whole
+        # backward + optimizer step on the stream, so the host -- and with it the next frame's upload and forward launches --
+        # stood still for the rest of the step (0.37 ms of an end-to-end frame at B = 5).  host_pose_output=False /
+        # CLSLAM_HOST_POSE=0 returns device tensors like the reference.
+        if host_pose_output is None:
+            host_pose_output = os.environ.get('CLSLAM_HOST_POSE', '1') != '0'
+        self.host_pose_output = bool(host_pose_output)
+        self._pose_host: Dict[int, Tensor] = {}
+        self._pose_staged = None
 
     # ============================================================
     # Data-parallel replay minibatch (new functionality; the reference has no multi-GPU adaptation)
@@ -348,6 +360,11 @@ class DepthPosePrediction:
                 self.optimizer.loss_guard = None
                 losses = self._staged_losses()
                 self._raise_on_nan(losses, undo_step=True)
+            if self._pose_staged is not None:
+                # the event _staged_losses() waited for covers the pose copy issued just before the loss copy
+                T = self._pose_host[self._pose_staged].clone()
+                outputs_eval['cam_T_cam', 0, -1], outputs_eval['cam_T_cam', 0, 1] = T[0], T[1]
+                self._pose_staged = None
         else:
             self._set_eval()
             self.engine.pack_if_needed()
@@ -541,7 +558,10 @@ class DepthPosePrediction:
             self._copy_stream = torch.cuda.Stream(device=dev)
         cur = torch.cuda.current_stream(dev)
         cs = self._copy_stream
-        cs.wait_stream(cur)                 # (allocator) blocks freed on the caller's stream may be handed out here
+        # No cs.wait_stream(cur): the device blocks are allocated under the copy stream (its own pool in torch's caching
+        # allocator; record_stream below defers their reuse until the engine's streams are past them), so the copies of
+        # frame N+1 need not wait for frame N's backward + optimizer step still queued on the caller's stream -- they cross
+        # PCIe underneath it.
         users = [cur] + [st for st in (self.engine.side_stream, self.engine.wg_stream) if st is not None]
         def copy(k):
             t = inputs[k].to(dev, non_blocking=True)
@@ -592,6 +612,11 @@ class DepthPosePrediction:
             if self._loss_host is None:
                 self._loss_host = torch.empty(18, dtype=torch.float32, pin_memory=True)
                 self._loss_event = torch.cuda.Event()
+            if train and self.host_pose_output and not graphed:
+                if B not in self._pose_host:
+                    self._pose_host[B] = torch.empty(2, B, 4, 4, dtype=torch.float32, pin_memory=True)
+                self._pose_host[B].copy_(self.engine.workspace(B).T, non_blocking=True)   # (2, B, 4, 4): frames -1, +1
+                self._pose_staged = B
             self._loss_host.copy_(losses, non_blocking=True)
             self._loss_event.record()
             if not train:

@@ -5,6 +5,7 @@
 
 #include <atomic>
 #include <mutex>
+#include <chrono>
 #include <thread>
 #include <vector>
 
@@ -144,7 +145,13 @@ void emu_sync_wave() {
 float* emu_wave_scratch() { return W->wave_scratch.data() + (size_t)(W->fibers[W->cur].tid / 64) * 256; }
 int emu_wave_phase() { return (int)W->wave_phase[W->fibers[W->cur].tid / 64]; }
 
-void emu_yield_os() { std::this_thread::yield(); }
+// A spinning consumer block gives its core away; on a loaded host (8 cores shared with a compiler) plain yields can burn
+// through the kernel's spin limit before the producer's thread is scheduled at all, so every 256th call sleeps.
+void emu_yield_os() {
+    static thread_local unsigned calls = 0;
+    if ((++calls & 255u) == 0) std::this_thread::sleep_for(std::chrono::microseconds(50));
+    else std::this_thread::yield();
+}
 
 void emu_launch(std::function<void()> body, dim3 grid, dim3 block) {
     const size_t nblocks = (size_t)grid.x * grid.y * grid.z;

@@ -230,3 +230,32 @@ def test_host_batch_upload_is_selective_asynchronous_and_invisible():
         results.append((out['depth', 0].clone(), out['cam_T_cam', 0, 1].clone(), float(losses['loss']), p.engine.w.clone()))
     for a, b in zip(results[0], results[1]):
         assert (a == b) if isinstance(a, float) else torch.equal(a, b)
+
+
+@pytest.mark.gpu
+def test_pose_is_handed_out_on_the_host_without_waiting_for_the_backward():
+    """adapt(online, training) returns outputs['cam_T_cam', 0, +-1] as host tensors staged behind the forward (what
+    slam.py:181-186 reads back every frame): bitwise the device result of host_pose_output=False, and reading them does not
+    wait for the backward + optimizer step still running on the stream."""
+    use_backend('hip')
+    B = 3
+    batch = {k: v.cuda() for k, v in synth.make_batch(B, H, W, seed=61).items()}
+    noise = {s: v.cuda() for s, v in synth.make_noise(B, H, W, seed=62).items()}
+    got = {}
+    for host in (True, False):
+        p = make_predictor(H, W, B, host_pose_output=host)
+        p.set_tie_break_noise(noise)
+        out, _ = p.adapt(None, dict(batch), steps=2)
+        for f in (-1, 1):
+            assert out['cam_T_cam', 0, f].is_cuda == (not host) and tuple(out['cam_T_cam', 0, f].shape) == (B, 4, 4)
+        # what slam.py does with it
+        T = torch.linalg.inv(out['cam_T_cam', 0, 1][0, :]).squeeze().cpu().detach().numpy()
+        assert T.shape == (4, 4)
+        got[host] = [out['cam_T_cam', 0, f].cpu().clone() for f in (-1, 1)]
+        torch.cuda.synchronize()
+    for a, b in zip(got[True], got[False]):
+        assert torch.equal(a, b)
+    # predict() / adapt(online, None) keep device tensors (their callers feed them back into device code)
+    p = make_predictor(H, W, B)
+    out, _ = p.adapt(dict(batch), None)
+    assert out['cam_T_cam', 0, 1].is_cuda
