@@ -267,14 +267,24 @@ extern "C" int clslam_conv2d_pick_config(const clslam_conv_desc* d) {
     // the step the B = 1 / B = 3 minibatches measured 1.60-1.76 / 2.39 ms with it against 1.55 / 2.33 ms without.  Hence the
     // fill rule: stream-K only where a launch has 32+ tiles of 128 px x 64 ch to cut.
     const bool sk_fill = (long long)d->batch * cdiv(d->out_h * d->out_w, 128) * cdiv(d->ch_out, 64) >= 32;
+    // ... and only where the pixel tiles are reasonably full: a 64-pixel run on a 2x4 image (the 64x128 test frames) is
+    // 12 % pixels and 88 % padding MFMAs (6x20 in 8x16 tiles, 47 %, still wins: 39.6 vs 32.2 TFLOP/s)
+    const int px = d->out_h * d->out_w;
+    auto full_enough = [&](int cfg) {
+        const int covered = cfg == 32 ? cdiv(px, 128) * 128 : cfg == 33 ? cdiv(px, 64) * 64
+                                      : cdiv(d->out_h, cfg == 30 ? 8 : 4) * (cfg == 30 ? 8 : 4) * cdiv(d->out_w, 16) * 16;
+        return px * 10 >= covered * 4;
+    };
+    int sk = 0;
     if (sk_ok && sk_fill && d->stride == 1 && d->out_h == d->in_h + 2 * d->pad - 2 && d->out_w == d->in_w + 2 * d->pad - 2) {
-        const long long units128 = (long long)d->batch * cdiv(d->out_h * d->out_w, 128) * cdiv(d->ch_out, 64) * (Cin / 16);
+        const long long units128 = (long long)d->batch * cdiv(px, 128) * cdiv(d->ch_out, 64) * (Cin / 16);
         // 256 -> 256 @12x40 at B = 5 is a tie stand-alone (74.0 tiled / 73.6) and 0.5 % slower inside the step: tiled
         const bool tie_case = Cin < 512 && d->ch_out >= 256 && d->out_w > 24 && units128 >= 1280 && M < 4000;
-        if (d->out_w <= 44 && Cin >= 256 && !tie_case) return units128 >= 1280 ? 32 : 33;
-        if (d->out_w <= 84 && d->out_w > 44 && Cin >= 256 && M >= 4000) return 30;
+        if (d->out_w <= 44 && Cin >= 256 && !tie_case) sk = units128 >= 1280 ? 32 : 33;
+        else if (d->out_w <= 84 && d->out_w > 44 && Cin >= 256 && M >= 4000) sk = 30;
     }
-    if (sk_ok && sk_fill && d->stride == 2 && d->out_w <= 24 && Cin >= 256) return 30;
+    if (sk_ok && sk_fill && d->stride == 2 && d->out_w <= 24 && Cin >= 256) sk = 30;
+    if (sk && full_enough(sk)) return sk;
     if (d->ksize == 3 && d->stride == 1 && d->out_h == d->in_h + 2 * d->pad - 2 && d->out_w == d->in_w + 2 * d->pad - 2) {
         if (d->out_w <= 24) return 22;                         // narrow images: run tiles
         // (config 26, 4x8 px x 32 ch tiles without overhang on 12x40, measured 67 vs 69 TFLOP/s for config 21: not picked)

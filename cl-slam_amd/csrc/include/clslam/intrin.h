@@ -10,6 +10,12 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// packed fp32 pairs (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 on gfx950: two lanes' worth of work per issue slot)
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 pk_abs(f32x2 a) { return __builtin_elementwise_abs(a); }
+__device__ __forceinline__ f32x2 pk_max(f32x2 a, float b) { const f32x2 v = {b, b}; return __builtin_elementwise_max(a, v); }
+__device__ __forceinline__ f32x2 pk_min(f32x2 a, float b) { const f32x2 v = {b, b}; return __builtin_elementwise_min(a, v); }
 
 namespace clslam {
 

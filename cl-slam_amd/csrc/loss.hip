@@ -25,6 +25,11 @@ __device__ __forceinline__ float div9(float x) {
     const float q = x * r;
     return fmaf(fmaf(-9.f, q, x), r, q);
 }
+__device__ __forceinline__ f32x2 div9(f32x2 x) {
+    const f32x2 r = {1.f / 9.f, 1.f / 9.f}, m9 = {-9.f, -9.f};
+    const f32x2 q = x * r;
+    return pk_fma(pk_fma(m9, q, x), r, q);
+}
 
 // Fused photometric map + auto-masking for the whole pyramid (one launch, grid (nblk, B, nscale)):
 // both reprojection maps of a pixel are evaluated in registers, the 4-way min / argmin is taken against
@@ -82,7 +87,10 @@ __global__ __launch_bounds__(256) void photo_automask_kernel(const float* __rest
                                                              unsigned char* __restrict__ sel_all, float* __restrict__ coef_sel_all,
                                                              float* __restrict__ partial_all, int B, int H, int W, int tilesX,
                                                              unsigned long long seed, unsigned long long rng_offset) {
-    __shared__ float tl[9][PA_PH * PA_PW];   // planes 0-2: target, 3-5: warped frame 0, 6-8: warped frame 1
+    // The two source frames of a pixel travel as ONE packed pair (f32x2 = v_pk_* arithmetic, ds_read_b64): the kernel is
+    // VALU-bound (~900 issue slots per pixel before, two thirds of them per frame), not LDS- or HBM-bound.
+    __shared__ float tl[3][PA_PH * PA_PW];   // target
+    __shared__ f32x2 tw[3][PA_PH * PA_PW];   // warped (frame 0, frame 1)
     __shared__ float red[4];
     const float C1 = 0.0001f, C2 = 0.0009f;
     const int b = blockIdx.y, sc = blockIdx.z;
@@ -100,12 +108,14 @@ __global__ __launch_bounds__(256) void photo_automask_kernel(const float* __rest
         const int r = e / PA_PW, c = e - r * PA_PW;
         // reflection padding; tiles overhanging the image clamp (those pixels are never consumed)
         const int yy = min(max(refl(y0 - 1 + r, H), 0), H - 1), xx = min(max(refl(x0 - 1 + c, W), 0), W - 1);
-        const int o = yy * W + xx;
+        const unsigned o = (unsigned)(yy * W + xx);
 #pragma unroll
         for (int c3 = 0; c3 < 3; ++c3) {
-            tl[c3][e] = tgt[(size_t)c3 * HW + o];
-            tl[3 + c3][e] = wp0[(size_t)c3 * HW + o];
-            tl[6 + c3][e] = wp1[(size_t)c3 * HW + o];
+            tl[c3][e] = (tgt + (size_t)c3 * HW)[o];
+            f32x2 v;
+            v.x = (wp0 + (size_t)c3 * HW)[o];
+            v.y = (wp1 + (size_t)c3 * HW)[o];
+            tw[c3][e] = v;
         }
     }
     __syncthreads();
@@ -116,48 +126,47 @@ __global__ __launch_bounds__(256) void photo_automask_kernel(const float* __rest
         const int ly = lp / PA_TW, lx = lp - ly * PA_TW;
         const int y = y0 + ly, x = x0 + lx;
         if (y >= H || x >= W) continue;
-        const int p = y * W + x;
-        float cm[2] = {0.f, 0.f}, l1[2] = {0.f, 0.f};   // per frame: sum_c clamp((1-SSIM)/2), sum_c |t - p|
-        float kc[2][9];
+        const unsigned p = (unsigned)(y * W + x);
+        f32x2 cm = {0.f, 0.f}, l1 = {0.f, 0.f};   // per frame: sum_c clamp((1-SSIM)/2), sum_c |t - p|
+        f32x2 kc[9];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             float tv[9];
             float sy = 0.f, syy = 0.f;
+            f32x2 sx = {0.f, 0.f}, sxx = {0.f, 0.f}, sxy = {0.f, 0.f}, xc = {0.f, 0.f};
 #pragma unroll
             for (int k = 0; k < 9; ++k) {
-                tv[k] = tl[c][(ly + k / 3) * PA_PW + lx + k % 3];
+                const int e = (ly + k / 3) * PA_PW + lx + k % 3;
+                tv[k] = tl[c][e];
                 sy += tv[k]; syy += tv[k] * tv[k];
+                const f32x2 xv = tw[c][e];
+                if (k == 4) xc = xv;
+                sx += xv; sxx += xv * xv; sxy += xv * tv[k];
             }
             const float mu_y = div9(sy);
             const float sig_y = div9(syy) - mu_y * mu_y;
-#pragma unroll
-            for (int f = 0; f < 2; ++f) {
-                float sx = 0.f, sxx = 0.f, sxy = 0.f, xc = 0.f;
-#pragma unroll
-                for (int k = 0; k < 9; ++k) {
-                    const float xv = tl[3 + f * 3 + c][(ly + k / 3) * PA_PW + lx + k % 3];
-                    if (k == 4) xc = xv;
-                    sx += xv; sxx += xv * xv; sxy += xv * tv[k];
-                }
-                const float mu_x = div9(sx);
-                const float sig_x = div9(sxx) - mu_x * mu_x, sig_xy = div9(sxy) - mu_x * mu_y;
-                const float n1 = 2.f * mu_x * mu_y + C1, n2 = 2.f * sig_xy + C2;
-                const float d1 = mu_x * mu_x + mu_y * mu_y + C1, d2 = sig_x + sig_y + C2;
-                const float inv_d = fast_rcp(d1 * d2);
-                const float S = (n1 * n2) * inv_d;
-                const float raw = (1.f - S) * 0.5f;
-                cm[f] += fminf(fmaxf(raw, 0.f), 1.f);
-                l1[f] += fabsf(tv[4] - xc);
-                if constexpr (TRAIN) {
-                    const float kf = (raw >= 0.f && raw <= 1.f) ? (0.85f / 3.f) * (-0.5f) / 9.f : 0.f;
-                    kc[f][c * 3 + 0] = kf * inv_d * (2.f * mu_y * (n2 - n1) - S * (2.f * mu_x * (d2 - d1)));
-                    kc[f][c * 3 + 1] = kf * inv_d * (-2.f * S * d1);
-                    kc[f][c * 3 + 2] = kf * inv_d * (2.f * n1);
-                }
+            const f32x2 mu_x = div9(sx);
+            const f32x2 sig_x = div9(sxx) - mu_x * mu_x, sig_xy = div9(sxy) - mu_x * mu_y;
+            const f32x2 n1 = 2.f * mu_x * mu_y + C1, n2 = 2.f * sig_xy + C2;
+            const f32x2 d1 = mu_x * mu_x + mu_y * mu_y + C1, d2 = sig_x + sig_y + C2;
+            const f32x2 dd = d1 * d2;
+            f32x2 inv_d;
+            inv_d.x = fast_rcp(dd.x); inv_d.y = fast_rcp(dd.y);
+            const f32x2 S = (n1 * n2) * inv_d;
+            const f32x2 raw = (1.f - S) * 0.5f;
+            cm += pk_min(pk_max(raw, 0.f), 1.f);
+            l1 += pk_abs(tv[4] - xc);
+            if constexpr (TRAIN) {
+                f32x2 kf;
+                kf.x = (raw.x >= 0.f && raw.x <= 1.f) ? (0.85f / 3.f) * (-0.5f) / 9.f : 0.f;
+                kf.y = (raw.y >= 0.f && raw.y <= 1.f) ? (0.85f / 3.f) * (-0.5f) / 9.f : 0.f;
+                kc[c * 3 + 0] = kf * inv_d * (2.f * mu_y * (n2 - n1) - S * (2.f * mu_x * (d2 - d1)));
+                kc[c * 3 + 1] = kf * inv_d * (-2.f * S * d1);
+                kc[c * 3 + 2] = kf * inv_d * (2.f * n1);
             }
         }
-        const float c2 = (0.85f / 3.f) * cm[0] + (0.15f / 3.f) * l1[0];
-        const float c3 = (0.85f / 3.f) * cm[1] + (0.15f / 3.f) * l1[1];
+        const float c2 = (0.85f / 3.f) * cm.x + (0.15f / 3.f) * l1.x;
+        const float c3 = (0.85f / 3.f) * cm.y + (0.15f / 3.f) * l1.y;
         float c0 = idmap[((size_t)0 * B + b) * HW + p];
         float c1 = idmap[((size_t)1 * B + b) * HW + p];
         if (noise) { c0 += noise[((size_t)b * 2 + 0) * HW + p]; c1 += noise[((size_t)b * 2 + 1) * HW + p]; }
@@ -174,7 +183,7 @@ __global__ __launch_bounds__(256) void photo_automask_kernel(const float* __rest
         if constexpr (TRAIN) {
             if (k >= 2) {
 #pragma unroll
-                for (int q = 0; q < 9; ++q) coef_sel[(size_t)q * HW + p] = (k == 2) ? kc[0][q] : kc[1][q];
+                for (int q = 0; q < 9; ++q) (coef_sel + (size_t)q * HW)[p] = (k == 2) ? kc[q].x : kc[q].y;
             }
         }
         s += m;

@@ -612,7 +612,7 @@ class DepthPosePrediction:
             if self._loss_host is None:
                 self._loss_host = torch.empty(18, dtype=torch.float32, pin_memory=True)
                 self._loss_event = torch.cuda.Event()
-            if train and self.host_pose_output and not graphed:
+            if train and self.host_pose_output:
                 if B not in self._pose_host:
                     self._pose_host[B] = torch.empty(2, B, 4, 4, dtype=torch.float32, pin_memory=True)
                 self._pose_host[B].copy_(self.engine.workspace(B).T, non_blocking=True)   # (2, B, 4, 4): frames -1, +1

@@ -140,6 +140,21 @@ void emu_sync_wave() {
     emu_switch(&f.sp, w->sched_sp);
 }
 
+// MFMA operand exchange in ONE runtime call (the emulated conv kernels spend their time here): lane l stores its a / b
+// operand, waits for the wave, returns the buffer of the phase it wrote in.
+float* emu_wave_exchange2(float a, float b) {
+    Worker* w = W;
+    Fiber& f = w->fibers[w->cur];
+    const unsigned wv = f.tid / 64, l = f.tid & 63;
+    float* s = w->wave_scratch.data() + (size_t)wv * 256 + w->wave_phase[wv] * 128;
+    s[l] = a;
+    s[64 + l] = b;
+    if (++w->wave_cnt[wv] == w->wave_live[wv]) { w->wave_cnt[wv] = 0; w->wave_gen[wv]++; w->wave_phase[wv] ^= 1; return s; }
+    f.wait_kind = 2; f.wait_gen = w->wave_gen[wv];
+    emu_switch(&f.sp, w->sched_sp);
+    return s;
+}
+
 // NOTE: a lane reads the exchange buffer of the phase it wrote in; the phase flips when the
 // last lane arrives, so readers must latch the pointer BEFORE the sync (intrin.h does).
 float* emu_wave_scratch() { return W->wave_scratch.data() + (size_t)(W->fibers[W->cur].tid / 64) * 256; }

@@ -8,6 +8,12 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// packed fp32 pairs (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 on gfx950: two lanes' worth of work per issue slot)
+inline f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+inline f32x2 pk_abs(f32x2 a) { return __builtin_elementwise_abs(a); }
+inline f32x2 pk_max(f32x2 a, float b) { const f32x2 v = {b, b}; return __builtin_elementwise_max(a, v); }
+inline f32x2 pk_min(f32x2 a, float b) { const f32x2 v = {b, b}; return __builtin_elementwise_min(a, v); }
 
 void emu_yield_os();   // emu_runtime.cpp
 
@@ -18,10 +24,7 @@ inline int lane_id() { return (int)(threadIdx.x & 63); }
 
 inline f32x16 mfma_32x32x2(float a, float b, f32x16 c) {
     const int l = lane_id();
-    float* s = emu_wave_scratch() + emu_wave_phase() * 128;
-    s[l] = a;
-    s[64 + l] = b;
-    emu_sync_wave();
+    const float* s = emu_wave_exchange2(a, b);
     const int j = l & 31, hi = l >> 5;
     for (int r = 0; r < 16; ++r) {
         const int i = (r & 3) + 8 * (r >> 2) + 4 * hi;
@@ -34,10 +37,7 @@ inline f32x16 mfma_32x32x2(float a, float b, f32x16 c) {
 
 inline f32x4 mfma_16x16x4(float a, float b, f32x4 c) {
     const int l = lane_id();
-    float* s = emu_wave_scratch() + emu_wave_phase() * 128;
-    s[l] = a;
-    s[64 + l] = b;
-    emu_sync_wave();
+    const float* s = emu_wave_exchange2(a, b);
     const int j = l & 15, g = l >> 4;
     for (int r = 0; r < 4; ++r) {
         const int i = 4 * g + r;

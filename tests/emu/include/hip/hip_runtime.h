@@ -50,6 +50,7 @@ inline float2 make_float2(float x, float y) { return float2{x, y}; }
 // Barrier across the block's fibers / across one 64-lane wave (emu_runtime.cpp).
 void emu_sync_block();
 void emu_sync_wave();
+float* emu_wave_exchange2(float a, float b);   // both MFMA operands of this lane out, the wave's exchange buffer back
 float* emu_wave_scratch();  // 2 x 64 x 2 floats of per-wave exchange space, double-buffered
 int emu_wave_phase();       // flips at each wave-collective
 inline void __syncthreads() { emu_sync_block(); }

@@ -16,7 +16,7 @@ from pathlib import Path
 TESTS = Path(__file__).resolve().parent
 ROOT = TESTS.parent
 REF = Path('/root/reference')
-H, W = 64, 128
+H, W = 64, 64
 
 
 def make_kitti_tree(root: Path, n: int, period: int) -> None:

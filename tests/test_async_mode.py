@@ -12,7 +12,7 @@ import torch
 import torch.multiprocessing as mp
 
 ROOT = Path(__file__).resolve().parents[1]
-H, W, B, FRAMES, EVERY = 64, 128, 2, 3, 1
+H, W, B, FRAMES, EVERY = 64, 64, 2, 3, 1
 
 
 def _worker(rank, world, port, out_dir):

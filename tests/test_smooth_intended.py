@@ -13,7 +13,7 @@ from emu_util import BACKENDS, use_backend
 from helpers import make_oracle
 from predictor_util import make_predictor
 
-H, W, B = 64, 128, 2
+H, W, B = 64, 64, 2
 
 
 @pytest.mark.parametrize('backend', BACKENDS)
