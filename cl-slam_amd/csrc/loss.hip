@@ -206,7 +206,10 @@ __global__ __launch_bounds__(256) void loss_bwd2_kernel(Pyramid pyr, const unsig
                                                         const float* __restrict__ P, const float* __restrict__ sample_w,
                                                         float* __restrict__ ddisp_up_all, float* __restrict__ dP_partial, int B,
                                                         int H, int W, float da, float db, int dmode, int tilesX) {
-    __shared__ float cs[9][LB_PH * LB_PW];
+    // coefficients pixel-major, 10 floats per pixel as five pairs (alpha_0 alpha_1)(alpha_2 beta_0)(beta_1 beta_2)
+    // (gamma_0 gamma_1)(gamma_2 -): a neighbour is five ds_read_b64 + five v_pk_fma instead of nine reads + nine FMAs
+    // (40-byte stride: conflict-free for 8-byte reads)
+    __shared__ f32x2 cs[LB_PH * LB_PW][5];
     __shared__ unsigned char ss[LB_PH * LB_PW];
     __shared__ float red[4][24];
     const int b = blockIdx.y, sc = blockIdx.z;
@@ -228,8 +231,15 @@ __global__ __launch_bounds__(256) void loss_bwd2_kernel(Pyramid pyr, const unsig
         const unsigned char sv = in ? sl[yy * W + xx] : (unsigned char)255;
         ss[e] = sv;
         const bool need = in && sv >= 2 && sv < 4;
+        const unsigned o = need ? (unsigned)(yy * W + xx) : 0u;
+        float v[10];
 #pragma unroll
-        for (int q = 0; q < 9; ++q) cs[q][e] = need ? coef[(size_t)q * HW + (size_t)yy * W + xx] : 0.f;
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { const float t = (coef + (size_t)(c * 3 + j) * HW)[o]; v[j * 3 + c] = need ? t : 0.f; }
+        v[9] = 0.f;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) { f32x2 t; t.x = v[2 * q]; t.y = v[2 * q + 1]; cs[e][q] = t; }
     }
     __syncthreads();
     const float* Ki = Kinv + (size_t)b * 16;
@@ -270,20 +280,21 @@ __global__ __launch_bounds__(256) void loss_bwd2_kernel(Pyramid pyr, const unsig
                 if (fi == 0) ddisp_up[(size_t)b * HW + pi] = 0.f;
                 continue;
             }
-            float sA[3] = {0.f, 0.f, 0.f}, sB[3] = {0.f, 0.f, 0.f}, sC[3] = {0.f, 0.f, 0.f};
+            f32x2 acc[5];
+#pragma unroll
+            for (int q = 0; q < 5; ++q) { acc[q].x = 0.f; acc[q].y = 0.f; }
 #pragma unroll 1
             for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
                 for (int dx = 0; dx < 3; ++dx) {
                     const int e = (ly + dy) * LB_PW + lx + dx;
-                    const float ww = ss[e] == want ? (dy == 0 ? wy[0] : dy == 1 ? wy[1] : wy[2]) * wx[dx] : 0.f;
+                    const float w1 = ss[e] == want ? (dy == 0 ? wy[0] : dy == 1 ? wy[1] : wy[2]) * wx[dx] : 0.f;
+                    const f32x2 ww = {w1, w1};
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        sA[c] = fmaf(ww, cs[c * 3 + 0][e], sA[c]);
-                        sB[c] = fmaf(ww, cs[c * 3 + 1][e], sB[c]);
-                        sC[c] = fmaf(ww, cs[c * 3 + 2][e], sC[c]);
-                    }
+                    for (int q = 0; q < 5; ++q) acc[q] = pk_fma(ww, cs[e][q], acc[q]);
                 }
+            const float sA[3] = {acc[0].x, acc[0].y, acc[1].x}, sB[3] = {acc[1].y, acc[2].x, acc[2].y},
+                        sC[3] = {acc[3].x, acc[3].y, acc[4].x};
             const bool own = ss[(ly + 1) * LB_PW + lx + 1] == want;
             const float disp = upsample_disp(disp_s + (size_t)b * h * w, h, w, H, W, y, x);
             const float dep = disp_to_depth_dev(disp, da, db, dmode);
