@@ -261,14 +261,15 @@ def main():
         step()
         torch.cuda.synchronize()
         agg = {}
-        for kind, cfg, flops, secs, desc in ops.profile_end():
+        for kind, cfg, flops, secs, desc, nbytes in ops.profile_end():
             if args.dump_convs:
                 us = secs * 1e6
                 print(f'# conv cfg{cfg:3d} {desc:40s} {flops / 1e9:7.2f} GF {us:8.1f} us {flops / us / 1e6:6.1f} TF', file=sys.stderr)
-            a = agg.setdefault((kind, cfg), [0.0, 0.0, 0])
+            a = agg.setdefault((kind, cfg), [0.0, 0.0, 0, 0.0])
             a[0] += flops
             a[1] += secs
             a[2] += 1
+            a[3] += nbytes
         p.engine.use_side_stream = True
         # kernel names as rocprofv3 prints them (template arguments TH, TW, BN, BK, MF, WGM, RUN, LDPAD, S, SK)
         patch = {10: '8, 16, 64, 16, 32, 2, false, 4, 1', 11: '8, 16, 32, 16, 32, 4, false, 4, 1', 12: '8, 16, 16, 16, 16, 4, false, 4, 1',
@@ -287,7 +288,7 @@ def main():
                       32: 'conv3x3_sk_kernel<8, 16, true, 1, 64, 4, 2>', 33: 'conv3x3_sk_kernel<4, 16, true, 1, 64, 4, 2>',
                       34: 'conv3x3_sk_kernel<8, 16, false, 1, 32, 4, 1>', 35: 'conv3x3_sk_kernel<4, 16, false, 1, 32, 2, 2>',
                       36: 'conv3x3_sk_kernel<4, 16, true, 1, 32, 2, 2>', 37: 'conv3x3_sk_kernel<8, 16, true, 1, 32, 4, 1>'})
-        (kind, cfg), (fl, tt, cnt) = max(agg.items(), key=lambda kv: kv[1][1])
+        (kind, cfg), (fl, tt, cnt, nb) = max(agg.items(), key=lambda kv: kv[1][1])
         all_fl = sum(a[0] for a in agg.values())
         all_t = sum(a[1] for a in agg.values())
         traffic = None
@@ -297,6 +298,7 @@ def main():
             pass
         roof = {'bound': 'mfma', 'achieved': round(fl / tt / 1e12, 2), 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': round(fl / tt / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': traffic,
+                'algorithmic_bytes_per_launch_avg': round(nb / cnt),
                 'kernel': names[cfg], 'launches_per_step': cnt,
                 'avg_launch_us': round(tt / cnt * 1e6, 2), 'flops_per_launch_avg': fl / cnt,
                 'all_conv_launches': {'achieved': round(all_fl / all_t / 1e12, 2), 'time_ms_per_step': round(all_t * 1e3, 3),

@@ -91,6 +91,21 @@ class TrainableLayout:
         return flat.view(shape)
 
 
+_STREAM_POOL: Dict[Any, Dict[str, Any]] = {}
+
+
+def _device_streams(device) -> Dict[str, Any]:
+    """side / wgrad / capture / tail streams of this process on `device` (created once)."""
+    if device.type != 'cuda':
+        return {}
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    pool = _STREAM_POOL.get(key)
+    if pool is None:
+        pool = {name: torch.cuda.Stream(device=device) for name in ('side', 'wg', 'capture', 'tail')}
+        _STREAM_POOL[key] = pool
+    return pool
+
+
 class Engine:
     def __init__(self, height: int, width: int, device: torch.device, *, min_depth: Optional[float],
                  max_depth: Optional[float], disparity_smoothness: float, velocity_loss_scaling: Optional[float],
@@ -113,6 +128,8 @@ class Engine:
         self.layout = TrainableLayout()
         n = self.layout.size
         self.w = torch.zeros(n, device=device)
+        self._wb_cache: Dict[str, Any] = {}
+        self._main = None
         self.g = torch.zeros(n, device=device)
         self.m = torch.zeros(n, device=device)
         self.v = torch.zeros(n, device=device)
@@ -128,11 +145,15 @@ class Engine:
         # the depth net and the pose net are independent until the loss stage (and their backward passes
         # after it): run the pose branch on a second HIP stream so its small 6x20 layers fill the CUs the
         # depth branch leaves idle at kernel tails
-        self.side_stream = torch.cuda.Stream(device=device) if device.type == 'cuda' else None
-        self.wg_stream = torch.cuda.Stream(device=device) if device.type == 'cuda' else None
+        # (the streams are shared by every engine of the process on this device: HIP spreads streams over four hardware
+        # queues, and a third predictor's twelfth stream lands on the queue of its own main stream -- 3.84 instead of
+        # 3.33 ms per step measured with three predictors alive)
+        pool = _device_streams(device)
+        self.side_stream = pool.get('side')
+        self.wg_stream = pool.get('wg')
         # split-K scratch of the small-M 3x3 convs: one zero-filled buffer per stream convs are launched on
-        self._conv_ws: Dict[int, torch.Tensor] = {}
-        self.capture_stream = torch.cuda.Stream(device=device) if device.type == 'cuda' else None
+        self._conv_ws: Dict[int, torch.Tensor] = pool.setdefault('conv_ws', {}) if pool else {}
+        self.capture_stream = pool.get('capture')
         for st in (self.side_stream, self.wg_stream, self.capture_stream):
             if st is not None:
                 self._conv_workspace(st.cuda_stream)
@@ -140,7 +161,7 @@ class Engine:
         # stream; the caller's stream does not wait for them, so the frozen encoders of step N+1 overlap the
         # xGMI all-reduce.  Whatever reads trainable state waits on the event (wait_training()).
         self.async_tail = False
-        self.tail_stream = torch.cuda.Stream(device=device) if device.type == 'cuda' else None
+        self.tail_stream = pool.get('tail')
         self._tail_event = None       # optimizer step in flight on tail_stream
         self._tail_open = False       # backward() left its reduction on tail_stream; adam() closes it
         self._capturing = False
@@ -174,6 +195,14 @@ class Engine:
                 raise ClslamError('module parameters were modified while newer adapted weights live in the engine; '
                                   'call sync_modules() first')
             self.pack()
+
+    def _on(self, st):
+        """context: the launches of the block go to stream `st`.  Outside graph capture this is ops.launch_on (no change of
+        torch's current stream, 0.3 us instead of 6): the blocks it wraps contain launches of clslam_hip.ops only."""
+        if st is None:
+            import contextlib
+            return contextlib.nullcontext()
+        return torch.cuda.stream(st) if self._capturing else ops.launch_on(st)
 
     def _use_tail(self) -> bool:
         return (self.async_tail and self.tail_stream is not None and self.device.type == 'cuda' and not self._capturing
@@ -365,12 +394,12 @@ class Engine:
             self._conv_ws[handle] = torch.zeros(self.CONV_WS_BYTES, dtype=torch.uint8, device=self.device)
             ops.set_conv_workspace(handle, self._conv_ws[handle])
 
-    def _encoder(self, e, bufs, n: int, stem_inputs, waits=None) -> List[torch.Tensor]:
+    def _encoder(self, e, bufs, n: int, stem_inputs, waits=None, stream=None) -> List[torch.Tensor]:
         """stem_inputs: list of (img_a, img_b|None, batch offset, count); returns the 5 NHWC features.
         waits: one event per stem launch (its input image still crossing PCIe) for the current stream to wait on."""
         for i, (img_a, img_b, off, cnt) in enumerate(stem_inputs):
             if waits is not None:
-                torch.cuda.current_stream(self.device).wait_event(waits[i])
+                (stream or torch.cuda.current_stream(self.device)).wait_event(waits[i])
             ops.stem_conv(img_a, img_b, e.stem_w, e.stem_scale, e.stem_shift, bufs.f0[off:off + cnt])
         ops.maxpool3x3s2(bufs.f0, bufs.pool)
         x = bufs.pool
@@ -390,15 +419,19 @@ class Engine:
         return feats
 
     def _wb(self, prefix: str, cout: int, cin: int, taps: int):
-        w = self._slot(self.w, prefix + '.weight', cout * taps * cin).view(cout, taps, cin)
-        b = self._slot(self.w, prefix + '.bias', cout)
-        return w, b
+        # views of the flat weight arena (allocated once, packed in place): built once per layer, ~70 lookups per step
+        hit = self._wb_cache.get(prefix)
+        if hit is None:
+            w = self._slot(self.w, prefix + '.weight', cout * taps * cin).view(cout, taps, cin)
+            b = self._slot(self.w, prefix + '.bias', cout)
+            hit = self._wb_cache[prefix] = (w, b)
+        return hit
 
     def _depth_decoder(self, ws, feats: List[torch.Tensor]) -> None:
         x = feats[4]
         # the disparity heads of scales 3..1 are leaves of the chain (only the view synthesis reads them): they go to
         # the wgrad stream, idle during the forward, instead of sitting between two convolutions of the chain
-        main = torch.cuda.current_stream(self.device) if self.device.type == 'cuda' else None
+        main = self._main
         leaf = self.wg_stream if (main is not None and self.use_side_stream and self.wg_stream is not None) else None
         forked = False
         for i in range(4, -1, -1):
@@ -417,7 +450,7 @@ class Engine:
                     ev = torch.cuda.Event()
                     ev.record(main)
                     leaf.wait_event(ev)
-                    with torch.cuda.stream(leaf):
+                    with self._on(leaf):
                         ops.dispconv_fwd(x, w.view(9, NUM_CH_DEC[i]), b, ws.disp[i])
                     forked = True
                 else:
@@ -448,12 +481,14 @@ class Engine:
         what the previous step computed: they are kept instead of recomputed (54 % of a step's forward
         flops).  Ignored when no valid features are held."""
         H, W = self.H, self.W
-        self._conv_workspace()
+        # the caller's stream, looked up ONCE per call (torch.cuda.current_stream() costs 3 us; it was asked 30x per step)
+        self._main = torch.cuda.current_stream(self.device) if self.device.type == 'cuda' else None
+        self._conv_workspace(None if self._main is None else self._main.cuda_stream)
         if inputs_ready is not None:
             # inputs still crossing PCIe on the caller's copy stream: events (rgb_aug[0], rgb_aug[-1], rgb_aug[+1], everything
             # there).  The depth net only reads rgb_aug[0], the pose net the three rgb_aug frames; the un-augmented
             # frames are first needed by the identity maps / the loss stage.
-            torch.cuda.current_stream(self.device).wait_event(inputs_ready[0])
+            self._main.wait_event(inputs_ready[0])
         aug = {f: self._img(inputs['rgb_aug', f, 0]) for f in (-1, 0, 1)}
         rgb = {f: self._img(inputs['rgb', f, 0]) for f in (-1, 0, 1)}
         B = aug[0].shape[0]
@@ -505,23 +540,25 @@ class Engine:
         wg = self.wg_stream if (self.use_side_stream and self.wg_stream is not None) else None
         if wg is not None:
             # the wgrad stream idles during the forward: the input-only work runs there, off the critical path
-            wg.wait_stream(torch.cuda.current_stream(self.device))
+            wg.wait_stream(self._main)
             if inputs_ready is not None:
                 wg.wait_event(inputs_ready[3])
-            with torch.cuda.stream(wg):
+            # (injected / captured noise is written by torch ops: they need torch's current stream switched)
+            with (torch.cuda.stream(wg) if (noise is not None or self._capturing) else ops.launch_on(wg)):
                 have_noise = identity_and_noise()
-                id_ready = torch.cuda.Event()
-                id_ready.record(wg)
+            id_ready = torch.cuda.Event()
+            id_ready.record(wg)
         if side is not None:
-            main = torch.cuda.current_stream(self.device)
+            main = self._main
             side.wait_stream(main)
 
             def pose_branch():
-                with torch.cuda.stream(side):
+                with self._on(side):
                     # pose pairs in temporal order (dpp.py:949-955): (-1, 0) and (0, +1), batched as 2B
                     pf4 = ws.pf4 if reuse else self._encoder(self.enc['pose_encoder'], ws.penc, 2 * B,
                                                              [(aug[-1], aug[0], 0, B), (aug[0], aug[1], B, B)],
-                                                             waits=None if inputs_ready is None else inputs_ready[1:3])[4]
+                                                             waits=None if inputs_ready is None else inputs_ready[1:3],
+                                                             stream=side)[4]
                     self.wait_training(side)      # the (frozen) encoder above does not need the optimizer step in flight
                     self._pose_decoder(ws, pf4)
                     return pf4
@@ -557,13 +594,13 @@ class Engine:
         ws.dfeats, ws.pf4 = dfeats, pf4
         # view synthesis + loss ------------------------------------------------------------------
         if inputs_ready is not None:
-            torch.cuda.current_stream(self.device).wait_event(inputs_ready[3])
+            self._main.wait_event(inputs_ready[3])
         K = self._mat(inputs['camera_matrix', 0])
         Kinv = self._mat(inputs['inv_camera_matrix', 0])
         ops.pose_to_proj(ws.pose, K, ws.T, ws.P)
         ops.warp_fwd_pyramid(ws.disp, rgb[-1], rgb[1], Kinv, ws.P, ws.depth, ws.warped, self.min_depth, self.max_depth)
         if id_ready is not None:
-            torch.cuda.current_stream(self.device).wait_event(id_ready)
+            self._main.wait_event(id_ready)
         else:
             have_noise = identity_and_noise()
         # all four scales in one launch; reprojection maps stay in registers, only the selected frame's
@@ -681,16 +718,17 @@ class Engine:
         c = ws.ctx
         H, W = self.H, self.W
         feats = ws.dfeats
+        self._main = torch.cuda.current_stream(self.device) if self.device.type == 'cuda' else None
         wg = self.wg_stream if (self.use_side_stream and self.wg_stream is not None) else None
         t.wt_ready = None
         if wg is None:
             self._transpose_decoder_weights(t)
         else:
-            wg.wait_stream(torch.cuda.current_stream(self.device))
-            with torch.cuda.stream(wg):
+            wg.wait_stream(self._main)
+            with self._on(wg):
                 self._transpose_decoder_weights(t)
-                t.wt_ready = torch.cuda.Event()
-                t.wt_ready.record(wg)
+            t.wt_ready = torch.cuda.Event()
+            t.wt_ready.record(wg)
         # loss -> disparity logits and pose-decoder output ----------------------------------------
         ops.loss_bwd2_pyramid(ws.disp, ws.sel, ws.coef, ws.warped, c.rgb[0], c.rgb[-1], c.rgb[1], c.Kinv, ws.P, c.sample_w,
                               t.ddisp_up, t.dp_partial, self.min_depth, self.max_depth)
@@ -700,9 +738,9 @@ class Engine:
         ops.pose_bwd(t.dp_partial, 4, t.nb2, ws.pose, c.K, c.d0, c.d1, c.sample_w, self.vel_scale, t.dpose)
         side = self.side_stream if (self.use_side_stream and self.side_stream is not None) else None
         if side is not None:
-            main = torch.cuda.current_stream(self.device)
+            main = self._main
             side.wait_stream(main)
-            with torch.cuda.stream(side):
+            with self._on(side):
                 self._backward_pose_decoder(ws, t, B, t.side)
             self._backward_depth_decoder(ws, t, B)
             main.wait_stream(side)
@@ -715,7 +753,7 @@ class Engine:
         if self._use_tail():
             # the partial buffers are complete on the current stream; the reduction, the all-reduce (caller, under
             # training_stream()) and Adam follow on the tail stream and nobody waits for them here
-            self.tail_stream.wait_stream(torch.cuda.current_stream(self.device))
+            self.tail_stream.wait_stream(self._main)
             with torch.cuda.stream(self.tail_stream):
                 ops.reduce_multi(t.table, len(t.items), self.g)
             self._tail_open = True
@@ -745,7 +783,7 @@ class Engine:
         of the rest of the chain once its dz exists, so those run on a third stream (`wg_stream`)."""
         H, W = self.H, self.W
         feats = ws.dfeats
-        main = torch.cuda.current_stream(self.device) if self.device.type == 'cuda' else None
+        main = self._main
         wg = self.wg_stream if (self.use_side_stream and self.wg_stream is not None) else None
         if wg is not None:
             wg.wait_stream(main)
@@ -767,7 +805,7 @@ class Engine:
             ev = torch.cuda.Event()
             ev.record(main)
             st.wait_event(ev)
-            with torch.cuda.stream(st):
+            with self._on(st):
                 fn()
 
         if t.wt_ready is not None:

@@ -22,7 +22,7 @@ def profile_begin(max_launches: int = 8192) -> None:
 
 
 def profile_end():
-    """-> [(kind, config, flops, seconds, description)] in launch order; disarms."""
+    """-> [(kind, config, flops, seconds, description, algorithmic_bytes)] in launch order; disarms."""
     global PROFILE
     meta, PROFILE = PROFILE, None
     cap = max(1, len(meta))
@@ -30,10 +30,10 @@ def profile_end():
     count = C.c_int(0)
     _lib.get_lib().call('clslam_conv_profile_end', C.cast(ms, C.c_void_p), cap, C.cast(C.pointer(count), C.c_void_p))
     if not _lib.get_lib().is_device:      # the emulator build has no timestamps
-        return [(k, cfg, fl, 0.0, desc) for k, cfg, fl, desc in meta]
+        return [(k, cfg, fl, 0.0, desc, nb) for k, cfg, fl, desc, nb in meta]
     if count.value != len(meta):
         raise _lib.ClslamError(f'profile_end: {count.value} timed launches for {len(meta)} conv2d calls')
-    return [(k, cfg, fl, ms[i] * 1e-3, desc) for i, (k, cfg, fl, desc) in enumerate(meta)]
+    return [(k, cfg, fl, ms[i] * 1e-3, desc, nb) for i, (k, cfg, fl, desc, nb) in enumerate(meta)]
 
 
 # These two helpers run ~1000 times per step; at B <= 2 the step is host-bound, so they avoid every avoidable
@@ -41,8 +41,36 @@ def profile_end():
 _raw_stream = torch._C._cuda_getCurrentRawStream if hasattr(torch._C, '_cuda_getCurrentRawStream') else None
 
 
+_FORCED_STREAM: Optional[int] = None
+
+
+class launch_on:
+    """`with launch_on(stream):` -- every launch of this module inside the block goes to `stream` (a torch.cuda.Stream).
+    Unlike `torch.cuda.stream()` (6 us per block, ~25 blocks per step: the B = 1 step is bound by the host) it does not touch
+    torch's current stream: only for blocks that contain nothing but launches of this module."""
+    __slots__ = ('handle', 'prev')
+
+    def __init__(self, stream):
+        self.handle = None if stream is None else stream.cuda_stream
+
+    def __enter__(self):
+        global _FORCED_STREAM
+        self.prev = _FORCED_STREAM
+        if self.handle is not None:
+            _FORCED_STREAM = self.handle
+        return self
+
+    def __exit__(self, *exc):
+        global _FORCED_STREAM
+        _FORCED_STREAM = self.prev
+        return False
+
+
 def _stream(t: torch.Tensor) -> int:
-    """raw hipStream_t of torch's current stream on t's device (0 = the emulator's only stream)"""
+    """raw hipStream_t the launch goes to: the launch_on() stream if one is set, else torch's current stream on t's device
+    (0 = the emulator's only stream)"""
+    if _FORCED_STREAM is not None:
+        return _FORCED_STREAM
     if t.is_cuda:
         if _raw_stream is not None:
             return _raw_stream(t.device.index)
@@ -105,8 +133,11 @@ def conv2d(src_a, weight, out, *, src_b=None, scale=None, shift=None, residual=N
                       0 if workspace is None else workspace.numel())
     if PROFILE is not None:     # armed by profile_begin(): the library timestamps the launch itself
         cfg = config if config >= 0 else _lib.get_lib().cdll.clslam_conv2d_pick_config(C.byref(d))
+        # algorithmic bytes: every operand once (source a as stored, i.e. before the nearest-2x upsampling)
+        nbytes = 4.0 * (src_a.numel() + (0 if src_b is None else src_b.numel()) + weight.numel() + out.numel() +
+                        (0 if residual is None else residual.numel()) + (0 if actgrad_src is None else actgrad_src.numel()))
         PROFILE.append(('conv', cfg, 2.0 * B * Ho * Wo * Cout * ksize * ksize * (Ca + Cb),
-                        f'B{B} {Hi}x{Wi} {Ca}+{Cb}->{Cout} k{ksize} s{stride} pad{pad}'))
+                        f'B{B} {Hi}x{Wi} {Ca}+{Cb}->{Cout} k{ksize} s{stride} pad{pad}', nbytes))
     _lib.get_lib().call('clslam_conv2d', C.byref(d), stream)
     return out
 

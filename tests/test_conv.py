@@ -224,6 +224,7 @@ def test_conv_profile_hook_times_every_launch(backend):
     assert ops.PROFILE is None and len(got) == 3
     assert [g[2] for g in got] == [2.0 * 480 * 64 * 9 * 32, 2.0 * 480 * 64 * 32, 2.0 * 480 * 64 * 9 * 32]
     assert got[2][1] == 21
+    assert got[0][5] == 4.0 * (x.numel() + w.numel() + out.numel())      # algorithmic bytes: every operand once
     if backend == 'hip':
         assert all(1e-7 < g[3] < 1e-2 for g in got), got
     ops.conv2d(x, w, out, ksize=3)          # disarmed again: plain launches

@@ -11,22 +11,23 @@ import torch, bench
 from clslam_hip import synth
 
 H, W = 192, 640
-for K in (0, 2, 4):
+for K in ([int(a) for a in sys.argv[1:]] or (0, 2, 4)):
     B = K + 1
     p = bench.build_predictor(H, W, B)
     batch = {k: v.cuda() for k, v in synth.make_batch(B, H, W, seed=0).items()}
-    for _ in range(5):
+    for _ in range(60):          # warm clocks: the spin below and a fresh predictor both let them drop
         p.adapt(None, batch, steps=1)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(20):
+    for _ in range(40):
         p.adapt(None, batch, steps=1)
     torch.cuda.synchronize()
-    eager = (time.perf_counter() - t0) / 20 * 1e3
-    spin = int(2.4e9 * 4e-3)          # ~4 ms of s_sleep at the shader clock
+    eager = (time.perf_counter() - t0) / 40 * 1e3
+    spin = int(2.4e9 * (2.5e-3 + 0.5e-3 * B))     # s_sleep cycles: outlasts the host's enqueue of one step (1.5-2 ms)
     ts = []
     for _ in range(8):
-        torch.cuda.synchronize()
+        for _ in range(3):
+            p.adapt(None, batch, steps=1)
         e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True)
         torch.cuda._sleep(spin)
         e0.record()
