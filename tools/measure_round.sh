@@ -16,7 +16,7 @@ prof() {   # name, env..., then bench args after --
     (cd /tmp && env "$@" rocprofv3 --kernel-trace --stats -d /tmp/prof_$name -o run -- python $OLDPWD/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-also > /tmp/prof_$name.log 2>&1)
     local db=$(ls /tmp/prof_$name/*/*.db /tmp/prof_$name/*.db 2>/dev/null | head -1)
     python tools/rocprof_summary.py $db $OUT/${TAG}_kernel_stats_$name.csv
-    if [ "$name" == "3streams" ]; then python tools/timeline.py $db > $OUT/${TAG}_timeline_one_step.txt 2>&1; fi
+    if [ "$name" == "3streams" ]; then python tools/timeline.py $db -5 > $OUT/${TAG}_timeline_one_step.txt 2>&1; fi
 }
 prof 3streams CLSLAM_SIDE_STREAM=1
 prof serial CLSLAM_SIDE_STREAM=0
