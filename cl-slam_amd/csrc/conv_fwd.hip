@@ -259,14 +259,16 @@ extern "C" int clslam_conv2d_pick_config(const clslam_conv_desc* d) {
                        d->config != -2;          // config -2: the tiled kernels only (fallback of clslam_conv2d below)
     static const int sk_all = getenv("CLSLAM_SK_ALL") ? atoi(getenv("CLSLAM_SK_ALL")) : 0;   // experiment knob
     if (sk_ok && sk_all && Cin >= sk_all) return d->stride == 2 ? (d->out_w <= 44 ? 31 : 30) : (d->out_w <= 44 ? 32 : 30);
-    // Measured per layer shape at B = 5 and B = 1 (tools/bench_conv.py, profiles/r02c_conv_microbench*.txt).  The choice
+    // Measured per layer shape at B = 5 and B = 1 (tools/bench_conv.py, profiles/r02d_conv_microbench*.txt).  The choice
     // between 128- and 64-pixel tiles is the number of (tile, chunk) units: fewer than five per workgroup and the smaller
-    // tile's finer cut wins.  Stand-alone the even split also wins on the small minibatches since the owner of a tile fetches
-    // its contributors' slabs four at a time (B = 1: 14.6 -> 34.5 TFLOP/s on layer4) -- but a stream-K launch holds every
-    // CU (two 220-VGPR waves per SIMD, 120 KB of LDS), so the other two streams of a step stand still behind it: inside
-    // the step the B = 1 / B = 3 minibatches measured 1.60-1.76 / 2.39 ms with it against 1.55 / 2.33 ms without.  Hence the
-    // fill rule: stream-K only where a launch has 32+ tiles of 128 px x 64 ch to cut.
-    const bool sk_fill = (long long)d->batch * cdiv(d->out_h * d->out_w, 128) * cdiv(d->ch_out, 64) >= 32;
+    // tile's finer cut wins.  Since the owner of a tile fetches its contributors' slabs four at a time the even split also
+    // wins when few tiles exist (B = 1: 14.6 -> 34.5 TFLOP/s on layer4).  A stream-K launch holds every CU (two 220-VGPR
+    // waves per SIMD, 120 KB of LDS), so the other two streams of the step stand still behind it; while the B <= 3 steps were
+    // bound by the host's launch path that cost more than the faster kernels gained (1.60-1.76 vs 1.55 ms at B = 1) and a
+    // 32-tile minimum kept stream-K off there.  With the launch path trimmed the balance flipped (B = 1: 1.29-1.33 vs
+    // 1.31-1.33 ms, B = 2 / 3 / 4: -2.8 / -2.7 / -1.7 %, B = 5: -0.4 %): no minimum any more (CLSLAM_SK_FILL=<tiles> restores one).
+    static const int sk_fill_min = getenv("CLSLAM_SK_FILL") ? atoi(getenv("CLSLAM_SK_FILL")) : 0;
+    const bool sk_fill = (long long)d->batch * cdiv(d->out_h * d->out_w, 128) * cdiv(d->ch_out, 64) >= sk_fill_min;
     // ... and only where the pixel tiles are reasonably full: a 64-pixel run on a 2x4 image (the 64x128 test frames) is
     // 12 % pixels and 88 % padding MFMAs (6x20 in 8x16 tiles, 47 %, still wins: 39.6 vs 32.2 TFLOP/s)
     const int px = d->out_h * d->out_w;
