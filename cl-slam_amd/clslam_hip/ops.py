@@ -78,6 +78,20 @@ def _stream(t: torch.Tensor) -> int:
     return 0
 
 
+_QUERY_CACHE: dict = {}
+
+
+def _query(name: str, *args) -> int:
+    """Launch-geometry queries of the library (pure functions of integer arguments): asked once, then remembered -- a bare
+    ctypes call costs ~10 us and fold_blocks() alone was asked ten times per step."""
+    lib = _lib._LIB or _lib.get_lib()
+    key = (id(lib), name, args)
+    v = _QUERY_CACHE.get(key)
+    if v is None:
+        v = _QUERY_CACHE[key] = getattr(lib.cdll, name)(*args)
+    return v
+
+
 def _p(t: Optional[torch.Tensor]):
     if t is None:
         return None
@@ -164,7 +178,7 @@ def weight_transpose(w, wt, ch_in_sel=None):
 
 
 def fold_blocks(batch, h, w, ch, pool) -> int:
-    return _lib.get_lib().cdll.clslam_fold_blocks(batch, h, w, ch, int(pool))
+    return _query('clslam_fold_blocks', batch, h, w, ch, int(pool))
 
 
 def fold_act_grad(dxp, yout, dz, *, h, w, ch, border, pool, act, bias_partial=None, disp_dz=None, disp_w=None):
@@ -232,7 +246,7 @@ def copy_multi(pairs, stream_ref=None):
 
 
 def colsum_blocks(rows: int) -> int:
-    return _lib.get_lib().cdll.clslam_colsum_blocks(rows)
+    return _query('clslam_colsum_blocks', rows)
 
 
 def colsum(x, partial, rows, ch):
@@ -276,7 +290,7 @@ def dispconv_bwd_data(dz, w, dxp, ch, accumulate):
 
 
 def dispconv_wgrad_blocks(pixels: int) -> int:
-    return _lib.get_lib().cdll.clslam_dispconv_wgrad_blocks(pixels)
+    return _query('clslam_dispconv_wgrad_blocks', pixels)
 
 
 def dispconv_wgrad(dz, x, partial):
@@ -314,7 +328,7 @@ def warp_fwd(disp_s, src_m1, src_p1, inv_k, proj, depth, warped, min_depth, max_
 
 
 def warp_bwd_blocks(H, W) -> int:
-    return _lib.get_lib().cdll.clslam_warp_bwd_blocks(H, W)
+    return _query('clslam_warp_bwd_blocks', H, W)
 
 
 def warp_bwd(dpred, disp_s, src_m1, src_p1, inv_k, proj, ddisp_up, dp_partial, min_depth, max_depth):
@@ -336,7 +350,7 @@ def photo_map(pred, target, out_map, coef, npred, batch, H, W):
 
 
 def automask_blocks(H, W) -> int:
-    return _lib.get_lib().cdll.clslam_automask_blocks(H, W)
+    return _query('clslam_automask_blocks', H, W)
 
 
 def automask(idmap, noise, rpmap, sel, partial, batch, H, W):
@@ -345,7 +359,7 @@ def automask(idmap, noise, rpmap, sel, partial, batch, H, W):
 
 
 def disp_mean_chunks() -> int:
-    return _lib.get_lib().cdll.clslam_disp_mean_chunks()
+    return _query('clslam_disp_mean_chunks')
 
 
 def disp_mean(disp, means):
@@ -398,7 +412,7 @@ def dwconv(x, weight, scale, shift, out, ksize, stride, act):
 
 
 def avgpool_chunks(hw: int) -> int:
-    return _lib.get_lib().cdll.clslam_avgpool_chunks(hw)
+    return _query('clslam_avgpool_chunks', hw)
 
 
 def global_avgpool(x, out, partial=None):
@@ -445,7 +459,7 @@ def disp_mean_pyramid(disps, means, H, W):
 
 
 def loss_bwd_blocks(H, W) -> int:
-    return _lib.get_lib().cdll.clslam_loss_bwd_blocks(H, W)
+    return _query('clslam_loss_bwd_blocks', H, W)
 
 
 def loss_bwd_pyramid(disps, sel, coef, warped, target, src_m1, src_p1, inv_k, proj, sample_w, ddisp_up, dp_partial,
@@ -479,7 +493,7 @@ def tie_break_noise(out, seed, offset):
 
 
 def smooth_intended_chunks() -> int:
-    return _lib.get_lib().cdll.clslam_smooth_intended_chunks()
+    return _query('clslam_smooth_intended_chunks')
 
 
 def smooth_intended_fwd(disps, rgb0, partial, H, W):
@@ -498,7 +512,7 @@ def smooth_intended_bwd(disps, rgb0, aux, sample_w, dz, H, W, smooth_scale):
 
 
 def loss_bwd2_blocks(H, W) -> int:
-    return _lib.get_lib().cdll.clslam_loss_bwd2_blocks(H, W)
+    return _query('clslam_loss_bwd2_blocks', H, W)
 
 
 def loss_bwd2_pyramid(disps, sel, coef_sel, warped, target, src_m1, src_p1, inv_k, proj, sample_w, ddisp_up, dp_partial,
