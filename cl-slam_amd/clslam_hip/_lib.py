@@ -31,6 +31,10 @@ class ConvDesc(C.Structure):
                 ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t)]
 
 
+class TransposeItem(C.Structure):
+    _fields_ = [('w', fptr), ('wt', fptr), ('ch_out', i32), ('taps', i32), ('ch_in', i32), ('ch_in_sel', i32)]
+
+
 class CopyItem(C.Structure):
     _fields_ = [('src', C.c_void_p), ('dst', C.c_void_p), ('bytes', C.c_size_t)]
 
@@ -50,6 +54,7 @@ _SIGNATURES = {
     'clslam_conv2d': [C.POINTER(ConvDesc), C.c_void_p],
     'clslam_conv2d_pick_config': [C.POINTER(ConvDesc)],
     'clslam_weight_transpose': [fptr, fptr, i32, i32, i32, i32, C.c_void_p],
+    'clslam_weight_transpose_multi': [C.POINTER(TransposeItem), i32, C.c_void_p],
     'clslam_fold_blocks': [i32, i32, i32, i32, i32],
     'clslam_fold_act_grad': [fptr, fptr, fptr, fptr, i32, i32, i32, i32, i32, i32, i32, i32, fptr, fptr, C.c_void_p],
     'clslam_wgrad_splits': [C.POINTER(ConvDesc), i32],

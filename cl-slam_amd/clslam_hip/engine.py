@@ -366,14 +366,15 @@ class Engine:
         t.dz = {k: torch.empty_like(v) for k, v in ws.x.items()}   # d(pre-ELU) of every upconv output
         pad_elems = max(B * ((H >> i) + 2) * ((W >> i) + 2) * NUM_CH_DEC[i] for i in range(5))
         t.dxp = [E(pad_elems), E(pad_elems)]
-        t.wt = E(256 * 9 * 256)
         t.wt_ready = None
         t.wt_dec = {}   # (i, j) -> flipped/transposed upconv_i_j weight for the dgrad convs (refreshed every backward)
+        t.wt_pose = {}  # 0 / 1 -> the same for pose_decoder pose_0 / pose_1
+        t.wt_table = None
         t.dz_p1 = torch.empty_like(ws.p1)
         t.dz_p0 = torch.empty_like(ws.p0)
         t.dz_sq = torch.empty_like(ws.sq)
         t.plan, t.items, t.table, t.disp_part = {}, [], None, {}
-        t.side = SimpleNamespace(wt=E(256 * 9 * 256))
+        t.side = SimpleNamespace()
         # fused bias-grad partials per layer: one row per fold workgroup (pooled folds run at the resolution of x)
         t.bias_part = {k: E(ops.fold_blocks(v.shape[0], v.shape[1], v.shape[2], v.shape[3], False) * v.shape[-1])
                        for k, v in ws.x.items()}
@@ -740,6 +741,8 @@ class Engine:
         if side is not None:
             main = self._main
             side.wait_stream(main)
+            if t.wt_ready is not None:
+                side.wait_event(t.wt_ready)     # transposed pose_0 / pose_1 weights
             with self._on(side):
                 self._backward_pose_decoder(ws, t, B, t.side)
             self._backward_depth_decoder(ws, t, B)
@@ -761,22 +764,29 @@ class Engine:
             ops.reduce_multi(t.table, len(t.items), self.g)
 
     def _transpose_decoder_weights(self, t) -> None:
-        """Flipped/transposed upconv weights for the dgrad convs.  They depend only on the weights, so all
-        nine are issued at the start of backward() on the wgrad stream, where they overlap the loss
-        backward instead of sitting between the dgrad convs of the critical path."""
-        for i in range(5):
-            ci = NUM_CH_DEC[i]
-            cin1 = ci + (NUM_CH_ENC[i - 1] if i > 0 else 0)
-            if (i, 1) not in t.wt_dec:
+        """Flipped/transposed weights for every dgrad conv of the step (nine depth-decoder upconvs, pose_0 / pose_1).
+        They depend only on the weights, so all eleven are produced by ONE launch at the start of backward() on the
+        wgrad stream, where it overlaps the loss backward instead of sitting between the dgrad convs of the critical
+        paths (eleven launches before: 0.06 ms of the B = 1 step)."""
+        if t.wt_table is None:
+            items = []
+            for i in range(5):
+                ci = NUM_CH_DEC[i]
+                cin1 = ci + (NUM_CH_ENC[i - 1] if i > 0 else 0)
                 t.wt_dec[i, 1] = torch.empty(ci, 9, ci, device=self.device)
-            w1, _ = self._wb(f'depth_decoder/upconv_{i}_1.conv.conv', ci, cin1, 9)
-            ops.weight_transpose(w1, t.wt_dec[i, 1], ch_in_sel=ci)   # only the up(x[i,0]) half: the skip half is frozen
-            if i < 4:
-                cin0 = NUM_CH_DEC[i + 1]
-                if (i, 0) not in t.wt_dec:
+                w1, _ = self._wb(f'depth_decoder/upconv_{i}_1.conv.conv', ci, cin1, 9)
+                items.append((w1, t.wt_dec[i, 1], ci))            # only the up(x[i,0]) half: the skip half is frozen
+                if i < 4:
+                    cin0 = NUM_CH_DEC[i + 1]
                     t.wt_dec[i, 0] = torch.empty(cin0, 9, ci, device=self.device)
-                w0, _ = self._wb(f'depth_decoder/upconv_{i}_0.conv.conv', ci, cin0, 9)
-                ops.weight_transpose(w0, t.wt_dec[i, 0])
+                    w0, _ = self._wb(f'depth_decoder/upconv_{i}_0.conv.conv', ci, cin0, 9)
+                    items.append((w0, t.wt_dec[i, 0], None))
+            for k in (0, 1):
+                t.wt_pose[k] = torch.empty(256, 9, 256, device=self.device)
+                wp, _ = self._wb(f'pose_decoder/pose_{k}', 256, 256, 9)
+                items.append((wp, t.wt_pose[k], None))
+            t.wt_table = ops.transpose_table(items)
+        ops.weight_transpose_multi(t.wt_table, self.w)
 
     def _backward_depth_decoder(self, ws, t, B: int) -> None:
         """dgrad chain (critical path) on the current stream; every weight/bias gradient is independent
@@ -868,14 +878,10 @@ class Engine:
                           self._slot(self.g, 'pose_decoder/pose_2.weight', 12 * 256).view(12, 256),
                           self._slot(self.g, 'pose_decoder/pose_2.bias', 12))
         self._wgrad(t, (ws.p0, None), (n2, h5, w5, 256), t.dz_p1, 'pose_decoder/pose_1', 256, 256, 9)
-        wp1, _ = self._wb('pose_decoder/pose_1', 256, 256, 9)
-        wt = scratch.wt[:256 * 9 * 256].view(256, 9, 256)
-        ops.weight_transpose(wp1, wt)
-        ops.conv2d(t.dz_p1, wt, t.dz_p0, ksize=3, pad=1, actgrad_src=ws.p0, actgrad_kind=ACT_RELU)
+        # (transposed weights: _transpose_decoder_weights, issued at the start of backward())
+        ops.conv2d(t.dz_p1, t.wt_pose[1], t.dz_p0, ksize=3, pad=1, actgrad_src=ws.p0, actgrad_kind=ACT_RELU)
         self._wgrad(t, (ws.sq, None), (n2, h5, w5, 256), t.dz_p0, 'pose_decoder/pose_0', 256, 256, 9)
-        wp0, _ = self._wb('pose_decoder/pose_0', 256, 256, 9)
-        ops.weight_transpose(wp0, wt)
-        ops.conv2d(t.dz_p0, wt, t.dz_sq, ksize=3, pad=1, actgrad_src=ws.sq, actgrad_kind=ACT_RELU)
+        ops.conv2d(t.dz_p0, t.wt_pose[0], t.dz_sq, ksize=3, pad=1, actgrad_src=ws.sq, actgrad_kind=ACT_RELU)
         self._wgrad(t, (ws.pf4, None), (n2, h5, w5, 256), t.dz_sq, 'pose_decoder/squeeze', 256, 512, 1, pad=0)
 
     # ------------------------------------------------------------------------------------------

@@ -177,6 +177,23 @@ def weight_transpose(w, wt, ch_in_sel=None):
     return wt
 
 
+def transpose_table(items):
+    """items: [(w (Cout,taps,Cin), wt, ch_in_sel | None)] -> a host table for weight_transpose_multi (build once: the
+    arena views and the wt buffers of an engine never move)"""
+    tab = (_lib.TransposeItem * len(items))()
+    for rec, (w, wt, sel) in zip(tab, items):
+        Cout, taps, Cin = w.shape
+        sel = Cin if sel is None else sel
+        assert wt.numel() >= sel * taps * Cout
+        rec.w, rec.wt, rec.ch_out, rec.taps, rec.ch_in, rec.ch_in_sel = _p(w), _p(wt), Cout, taps, Cin, sel
+    return tab
+
+
+def weight_transpose_multi(table, stream_ref):
+    """every weight tensor of `table` flipped / transposed for its dgrad convolution, in one launch"""
+    _lib.get_lib().call('clslam_weight_transpose_multi', table, len(table), _stream(stream_ref))
+
+
 def fold_blocks(batch, h, w, ch, pool) -> int:
     return _query('clslam_fold_blocks', batch, h, w, ch, int(pool))
 

@@ -27,6 +27,27 @@ __global__ void weight_transpose_kernel(const float* __restrict__ w, float* __re
     }
 }
 
+// Up to kTransposeBatch weight tensors in one launch (table by value in the kernel arguments; blockIdx.y = item)
+constexpr int kTransposeBatch = 16;
+struct TransposeBatch {
+    const float* w[kTransposeBatch];
+    float* wt[kTransposeBatch];
+    int cout[kTransposeBatch], taps[kTransposeBatch], cin[kTransposeBatch], cin_sel[kTransposeBatch];
+};
+__global__ void weight_transpose_multi_kernel(TransposeBatch b) {
+    const int it = blockIdx.y;
+    const float* __restrict__ w = b.w[it];
+    float* __restrict__ wt = b.wt[it];
+    const int Cout = b.cout[it], taps = b.taps[it], Cin = b.cin[it];
+    const int total = b.cin_sel[it] * taps * Cout;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int co = i % Cout;
+        const int t2 = (i / Cout) % taps;
+        const int ci = i / (Cout * taps);
+        wt[i] = w[((size_t)co * taps + (taps - 1 - t2)) * Cin + ci];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // dz[b,y,x,c] = act'(yout[b,y,x,c]) * sum_{(Y,X) in footprint(y,x)} sum_{P -> (Y,X)} dxp[b,P,c]
 // disp_dz / disp_w (optional, pool == 0, e == 1): the dispconv head hanging off the same activation
@@ -453,6 +474,28 @@ extern "C" int clslam_weight_transpose(const float* w, float* wt, int ch_out, in
     hipLaunchKernelGGL(weight_transpose_kernel, dim3(min(1024, cdiv(total, 256))), dim3(256), 0, (hipStream_t)stream,
                        w, wt, ch_out, taps, ch_in, ch_in_sel);
     return check_launch("weight_transpose");
+}
+
+extern "C" int clslam_weight_transpose_multi(const clslam_transpose_item* items, int nitems, void* stream) {
+    CLSLAM_REQUIRE(nitems >= 0 && (items || nitems == 0), "weight_transpose_multi: bad args");
+    for (int base = 0; base < nitems; base += kTransposeBatch) {
+        TransposeBatch b;
+        int n = 0, largest = 0;
+        for (int i = base; i < nitems && n < kTransposeBatch; ++i) {
+            const clslam_transpose_item& t = items[i];
+            CLSLAM_REQUIRE(t.w && t.wt && t.ch_in_sel <= t.ch_in && t.ch_out > 0 && t.taps > 0, "weight_transpose_multi: bad item %d", i);
+            if (t.ch_in_sel == 0) continue;
+            b.w[n] = t.w; b.wt[n] = t.wt; b.cout[n] = t.ch_out; b.taps[n] = t.taps; b.cin[n] = t.ch_in; b.cin_sel[n] = t.ch_in_sel;
+            largest = std::max(largest, t.ch_in_sel * t.taps * t.ch_out);
+            ++n;
+        }
+        if (!n) continue;
+        hipLaunchKernelGGL(weight_transpose_multi_kernel, dim3(std::min(256, cdiv(largest, 256)), n), dim3(256), 0,
+                           (hipStream_t)stream, b);
+        const int rc = check_launch("weight_transpose_multi");
+        if (rc != CLSLAM_OK) return rc;
+    }
+    return CLSLAM_OK;
 }
 
 extern "C" int clslam_fold_blocks(int batch, int h, int w, int ch, int pool) {

@@ -91,6 +91,15 @@ int clslam_conv2d_pick_config(const clslam_conv_desc* desc);
 /* wt[ci][taps-1-t][co] = w[co][t][ci] for ci < ch_in_sel: the weights of the dgrad-as-conv.    */
 int clslam_weight_transpose(const float* w, float* wt, int ch_out, int taps, int ch_in, int ch_in_sel,
                             void* stream);
+/* The same for nitems weight tensors in ONE launch (items is a HOST array, passed to the kernel by value): the eleven
+ * dgrad weight sets of a backward pass (nine depth_decoder upconvs, pose_decoder.py:40-47 pose_0 / pose_1) depend on
+ * the weights only and are produced together at its start.                                                          */
+typedef struct clslam_transpose_item {
+    const float* w;
+    float* wt;
+    int ch_out, taps, ch_in, ch_in_sel;
+} clslam_transpose_item;
+int clslam_weight_transpose_multi(const clslam_transpose_item* items, int nitems, void* stream);
 /* dz = act'(yout) * fold(dxp): dxp is the gradient w.r.t. the PADDED conv input
  * [B][h+2*border][w+2*border][ch_stride]; border=1 folds the reflection border back
  * (ReflectionPad2d backward), pool=1 sums each 2x2 block (nearest-2x upsample backward, output

@@ -140,3 +140,26 @@ def test_reduce_multi_all_split_regimes(backend):
     items2 = [(p, again[o.storage_offset():o.storage_offset() + n], n, s) for (p, o, n, s) in items]
     ops.reduce_multi(ops.make_reduce_table(items2, dev), len(items2), again)
     assert torch.equal(again, out)          # fixed summation order: bitwise reproducible
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_weight_transpose_multi_equals_single_launches(backend):
+    """clslam_weight_transpose_multi: every item of the table is bitwise what clslam_weight_transpose produces for it
+    (including a channel-selected item, the dgrad weights of a skip-concat conv)."""
+    dev = use_backend(backend)
+    g = torch.Generator().manual_seed(5)
+    shapes = [(16, 9, 16, None), (32, 9, 96, 32), (256, 9, 256, None), (64, 1, 128, None), (16, 9, 32, 16)]
+    items, refs = [], []
+    for cout, taps, cin, sel in shapes:
+        w = torch.randn(cout, taps, cin, generator=g).to(dev)
+        s = cin if sel is None else sel
+        wt = torch.full((s, taps, cout), float('nan'), device=dev)
+        ref = torch.empty(s, taps, cout, device=dev)
+        ops.weight_transpose(w, ref, ch_in_sel=sel)
+        expect = w[:, :, :s].flip(1).permute(2, 1, 0).contiguous()
+        assert torch.equal(ref.cpu(), expect.cpu())
+        items.append((w, wt, sel)); refs.append(ref)
+    table = ops.transpose_table(items)
+    ops.weight_transpose_multi(table, items[0][0])
+    for (w, wt, sel), ref in zip(items, refs):
+        assert torch.equal(wt.cpu(), ref.cpu())
