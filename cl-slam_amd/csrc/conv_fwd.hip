@@ -286,11 +286,13 @@ extern "C" int clslam_conv2d_pick_config(const clslam_conv_desc* d) {
         else if (d->out_w <= 84 && d->out_w > 44 && Cin >= 256 && M >= 4000) sk = 30;
     }
     if (sk_ok && sk_fill && d->stride == 2 && d->out_w <= 24 && Cin >= 256) sk = 30;
+    // the pose encoder's layer2.0 (64 -> 128, stride 2, 2B images): 74.7 vs 66.2 TFLOP/s; at B = 5 (M = 9600) the tiled kernel wins
+    if (sk_ok && sk_fill && d->stride == 2 && d->out_w > 24 && d->out_w <= 84 && M >= 16000) sk = 30;
     if (sk && full_enough(sk)) return sk;
     if (d->ksize == 3 && d->stride == 1 && d->out_h == d->in_h + 2 * d->pad - 2 && d->out_w == d->in_w + 2 * d->pad - 2) {
         if (d->out_w <= 24) return 22;                         // narrow images: run tiles
         // (config 26, 4x8 px x 32 ch tiles without overhang on 12x40, measured 67 vs 69 TFLOP/s for config 21: not picked)
-        return M >= 30000 ? 20 : 21;                           // 20/21/22 = 12/17/18 with conflict-free LDS rows
+        return M >= 16000 ? 20 : 21;                           // 20/21/22 = 12/17/18 with conflict-free LDS rows (24x80 at 2B: 91.5 vs 88.4)
     }
     if (d->ksize == 3 && d->stride == 2 && d->out_h == (d->in_h + 2 * d->pad - 3) / 2 + 1 && d->out_w == (d->in_w + 2 * d->pad - 3) / 2 + 1)
         return 23;
