@@ -94,3 +94,27 @@ def test_single_weight_broadcasts_over_the_batch(backend):
         _, li = p.adapt({k: v[i:i + 1].clone() for k, v in two.items()}, None)
         parts.append(float(li['reprojection_loss/scale_0']))
     assert abs(float(l2['reprojection_loss/scale_0']) - sum(parts)) < 1e-5 * sum(parts)
+
+
+def test_launch_on_steers_launches_and_restores_on_error():
+    """ops.launch_on: launches inside the block go to the given stream's raw handle, nested blocks restore the outer one,
+    an exception leaves no override behind (the engine's side-stream blocks rely on it instead of torch.cuda.stream())."""
+    from clslam_hip import ops
+
+    class FakeStream:
+        def __init__(self, h):
+            self.cuda_stream = h
+    t = torch.zeros(1)
+    assert ops._FORCED_STREAM is None and ops._stream(t) == 0
+    with ops.launch_on(FakeStream(11)):
+        assert ops._stream(t) == 11
+        with ops.launch_on(FakeStream(22)):
+            assert ops._stream(t) == 22
+        assert ops._stream(t) == 11
+        with ops.launch_on(None):                 # no stream: a no-op block
+            assert ops._stream(t) == 11
+    assert ops._FORCED_STREAM is None
+    with pytest.raises(ValueError):
+        with ops.launch_on(FakeStream(33)):
+            raise ValueError('boom')
+    assert ops._FORCED_STREAM is None and ops._stream(t) == 0
