@@ -25,9 +25,12 @@ from typing import Any, Dict, Optional, Tuple
 import torch
 
 
+ABORT_FRAME = -2.0        # frame marker of a snapshot posted by a trainer that failed: releases the inference replica
+
+
 class AsyncAdaptation:
     def __init__(self, predictor, group=None, sync_every: int = 5, trainer_group=None, trainer_global_batch: Optional[int] = None,
-                 trainer_shard_offset: int = 0) -> None:
+                 trainer_shard_offset: int = 0, transfer_timeout_s: float = 120.0) -> None:
         import torch.distributed as dist
         if not dist.is_initialized():
             raise RuntimeError('torch.distributed is not initialised')
@@ -40,6 +43,7 @@ class AsyncAdaptation:
             raise ValueError('the asynchronous mode needs an inference replica and at least one training replica')
         self.role = 'inference' if self.rank_in_group == 0 else 'trainer'
         self.sync_every = int(sync_every)
+        self.transfer_timeout_s = float(transfer_timeout_s)
         self.leader = dist.get_global_rank(group, 1) if group is not None else 1        # first trainer: broadcast source
         eng = predictor.engine
         self._n = eng.layout.size
@@ -59,7 +63,7 @@ class AsyncAdaptation:
             predictor.enable_data_parallel(trainer_global_batch, trainer_shard_offset, process_group=trainer_group)
 
     # ------------------------------------------------------------------------------------------------------------
-    def _post(self, frame: int) -> None:
+    def _post(self, frame: int, abort: bool = False) -> None:
         eng = self.p.engine
         if self.role == 'trainer':
             if self._work is not None:
@@ -67,11 +71,22 @@ class AsyncAdaptation:
             eng.wait_training()                       # the optimizer step in flight belongs to this snapshot
             self._staging[:self._n].copy_(eng.w)
             self._staging[self._n] = float(eng.adam_step_count)
-            self._staging[self._n + 1] = float(frame)
+            self._staging[self._n + 1] = ABORT_FRAME if abort else float(frame)
         elif self._work is not None:
             self._install(block=True)                 # one transfer in flight at a time
         self._work = self.dist.broadcast(self._staging, src=self.leader, group=self.group, async_op=True)
         self._posted_frame = frame
+
+    def _bounded_wait(self) -> None:
+        """host-side wait for the transfer in flight with a deadline: a peer that died without posting its side must not park
+        this replica forever"""
+        import time
+        deadline = time.monotonic() + self.transfer_timeout_s
+        while not self._work.is_completed():
+            if time.monotonic() > deadline:
+                raise RuntimeError(f'weight broadcast of frame {self._posted_frame} did not complete within '
+                                   f'{self.transfer_timeout_s:.0f} s: peer replica lost?')
+            time.sleep(0.0005)
 
     def _install(self, block: bool) -> bool:
         """inference replica: swap in the received arena if the transfer has completed"""
@@ -79,9 +94,13 @@ class AsyncAdaptation:
             return False
         if not block and not self._work.is_completed():
             return False
+        if block:
+            self._bounded_wait()
         self._work.wait()
         self._work = None
         meta = self._staging[self._n:].cpu()
+        if float(meta[1]) == ABORT_FRAME:
+            raise RuntimeError('the training replica failed and released the inference replica (see its exception)')
         self.weights_step, self.weights_frame = int(meta[0]), int(meta[1])
         self.p.engine.install_weights(self._staging[:self._n], self.weights_step)
         self.installs += 1
@@ -93,7 +112,20 @@ class AsyncAdaptation:
         """One camera frame.  Trainers: adapt(online, training, steps) (slam.py:174-176).  Inference replica:
         adapt(online, None) = forward only (slam.py:178), with whatever weights are installed."""
         if self.role == 'trainer':
-            out = self.p.adapt(online_data, training_data if training_data is not None else online_data, steps=steps)
+            # The snapshot broadcast (communicator `group`) and the gradient all-reduce (communicator `trainer_group`) are two
+            # RCCL communicators on one device with no ordering between them: both holding channels and CUs while one of them
+            # spins on a slow peer is a known way to deadlock.  They are serialised here -- the broadcast in flight is waited
+            # for (stream-ordered, the host does not block) before this frame's training step and its all-reduce go out.
+            if self._work is not None:
+                self._work.wait()
+                self._work = None
+            try:
+                out = self.p.adapt(online_data, training_data if training_data is not None else online_data, steps=steps)
+            except Exception:
+                # e.g. RuntimeError('NaN loss'): release the inference replica with an abort marker at its next receive
+                self._post(frame, abort=True)
+                self.flush()
+                raise
         else:
             self._install(block=False)
             self.used_weights_frame = self.weights_frame      # version this frame's prediction is made with
@@ -111,6 +143,7 @@ class AsyncAdaptation:
             if self.role == 'inference':
                 self._install(block=True)
             else:
+                self._bounded_wait()
                 self._work.wait()
                 self._work = None
 

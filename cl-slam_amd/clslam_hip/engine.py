@@ -166,8 +166,14 @@ class Engine:
         self._tail_open = False       # backward() left its reduction on tail_stream; adam() closes it
         self._capturing = False
         self.depth_first = os.environ.get('CLSLAM_DEPTH_FIRST', '1') != '0'
-        self.noise_seed = (int(torch.initial_seed()) * 0x9E3779B97F4A7C15 + 0x7F4A7C15) & 0xFFFFFFFFFFFFFFFF or 1
+        # tie-break noise drawn in the loss kernel (Philox): keyed by the seed of torch's generator of this device, re-read on
+        # every forward -- torch.manual_seed() after construction re-keys the stream and restarts its draw counter, like the
+        # global generator the reference draws from (dpp.py:1055-1056).  noise_stream = the data-parallel shard offset: ranks
+        # seeded identically still draw different fields for their different samples.
+        self._noise_torch_seed = None
+        self.noise_seed = 1
         self.noise_draws = 0
+        self.noise_stream = 0
         self.use_side_stream = os.environ.get('CLSLAM_SIDE_STREAM', '1') != '0'
         # steps 2..S of adapt(steps=S) keep the frozen encoders' features (see forward)
         self.reuse_frozen_features = os.environ.get('CLSLAM_REUSE_FROZEN', '1') != '0'
@@ -489,7 +495,11 @@ class Engine:
             # inputs still crossing PCIe on the caller's copy stream: events (rgb_aug[0], rgb_aug[-1], rgb_aug[+1], everything
             # there).  The depth net only reads rgb_aug[0], the pose net the three rgb_aug frames; the un-augmented
             # frames are first needed by the identity maps / the loss stage.
-            self._main.wait_event(inputs_ready[0])
+            # _img() converts non-fp32 / non-contiguous images with a torch kernel on the MAIN stream: that kernel must not
+            # read planes still in flight on the copy stream, so a batch that needs a conversion waits for all of it
+            needs_conversion = any(inputs[k, f, 0].dtype != torch.float32 or not inputs[k, f, 0].is_contiguous()
+                                   for k in ('rgb_aug', 'rgb') for f in (-1, 0, 1))
+            self._main.wait_event(inputs_ready[3 if needs_conversion else 0])
         aug = {f: self._img(inputs['rgb_aug', f, 0]) for f in (-1, 0, 1)}
         rgb = {f: self._img(inputs['rgb', f, 0]) for f in (-1, 0, 1)}
         B = aug[0].shape[0]
@@ -612,8 +622,8 @@ class Engine:
         else:
             # dpp.py:1055-1056 draws randn * 1e-5 on the compute device every scale, every step: here inside the kernel
             # (Philox keyed by torch's seed, one draw offset per forward) -- no noise tensor is written or read
-            self.noise_draws += 1
-            ops.photo_automask_pyramid_rng(ws.warped, rgb[0], ws.idmap, self.noise_seed, self.noise_draws, ws.sel,
+            seed, offset = self._next_noise_draw()
+            ops.photo_automask_pyramid_rng(ws.warped, rgb[0], ws.idmap, seed, offset, ws.sel,
                                            ws.coef if train else None, ws.partial, B, H, W)
         ops.disp_mean_pyramid(ws.disp, ws.means, H, W)
         n_smooth = 0 if (smooth_w is None or self.smooth_intended) else int(smooth_w.numel())
@@ -639,6 +649,26 @@ class Engine:
                                  aux=aux if n_smooth else None, B=B, rgb0=rgb0)
         ws.frozen_valid = True      # encoder features + identity maps of THESE inputs and encoder weights are held
         return self._outputs(ws, B), ws.losses
+
+    def _next_noise_draw(self) -> Tuple[int, int]:
+        """(Philox key, draw offset) of this forward's tie-break noise.  On the GPU the draw counter IS the device generator's
+        Philox offset (advanced by 4 per forward like a torch kernel drawing up to four values per thread would): manual_seed,
+        get_state / set_state of torch's generator reproduce the stream exactly as they do for the reference's torch.randn."""
+        if self.device.type == 'cuda':
+            gen = torch.cuda.default_generators[self.device.index if self.device.index is not None else torch.cuda.current_device()]
+            ts = int(gen.initial_seed())
+            off = int(gen.get_offset())
+            gen.set_offset(off + 4)
+            self.noise_draws = off // 4 + 1
+        else:           # the test emulator's CPU generator has no offset: a counter that restarts when the seed changes
+            ts = int(torch.default_generator.initial_seed())
+            if ts != self._noise_torch_seed:
+                self.noise_draws = 0
+            self.noise_draws += 1
+        if ts != self._noise_torch_seed:
+            self._noise_torch_seed = ts
+            self.noise_seed = (ts * 0x9E3779B97F4A7C15 + 0x7F4A7C15) & 0xFFFFFFFFFFFFFFFF or 1
+        return self.noise_seed, (int(self.noise_stream) << 40) | self.noise_draws
 
     def _img(self, t: torch.Tensor) -> torch.Tensor:
         if t.dtype != torch.float32 or not t.is_contiguous():

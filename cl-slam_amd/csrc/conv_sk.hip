@@ -24,6 +24,9 @@
 // Same fused epilogue and operand convention as conv_patch.hip (lane's float4 = four consecutive k-steps).
 #include "common.h"
 
+#include <mutex>
+#include <unordered_map>
+
 namespace clslam {
 
 __device__ float g_zero_page[64];   // 256 B of zeros: the DMA source of padded / out-of-range rows
@@ -49,6 +52,7 @@ struct SkK {
     long long units;
     float* slabs;        // [G][BM*BN] raw partial tiles
     unsigned* flags;     // [G], zero on entry, reset by the consumer
+    unsigned epoch;      // value a producer publishes in this launch (non-zero, different for consecutive eager launches)
     int dbg;             // measurement probes (CLSLAM_SK_DBG): 1 no epilogue, 2 no hand-off, 4 no MFMA, 8 no DMA
 };
 
@@ -264,7 +268,9 @@ __global__ __launch_bounds__(NWM * NWN * 64) void conv3x3_sk_kernel(SkK p) {
             for (int g2 = grp - 1; g2 >= 0 && (long long)(g2 + 1) * p.units / p.G > tile_first; --g2) ++ncon;
             for (int q = tid; q < ncon; q += NT) {
                 unsigned spins = 0;
-                while (coherent_load_u32(&p.flags[grp - 1 - q]) == 0u && ++spins < kSkSpinLimit) spin_pause();
+                // wait for THIS launch's epoch: a flag a late producer of an earlier, timed-out launch sets after its consumer
+                // gave up carries that launch's epoch and cannot be mistaken for a slab of this one
+                while (coherent_load_u32(&p.flags[grp - 1 - q]) != p.epoch && ++spins < kSkSpinLimit) spin_pause();
                 if (spins >= kSkSpinLimit) s_flag_ok = 0;
                 uncounted_flag_store(&p.flags[grp - 1 - q], 0u);   // zero again for the next launch on this stream
             }
@@ -381,7 +387,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void conv3x3_sk_kernel(SkK p) {
         dma_wait_all();             // this wave's pieces of unit k have landed (and its slab stores are acknowledged) ...
         wg_barrier_keep_dma();      // ... everybody's have, and nobody still reads the other stage
         if (publish_pending) {      // the partial slab parked during the previous unit is complete in memory: publish it
-            if (tid == 0) uncounted_flag_store(&p.flags[grp], 1u);
+            if (tid == 0) uncounted_flag_store(&p.flags[grp], p.epoch);
             publish_pending = false;
         }
         compute(lds + (k & 1) * STAGE, [&]() {
@@ -402,8 +408,37 @@ __global__ __launch_bounds__(NWM * NWN * 64) void conv3x3_sk_kernel(SkK p) {
     if (publish_pending) {          // the parked partial was this workgroup's last piece of work
         stores_complete();
         __syncthreads();
-        if (tid == 0) uncounted_flag_store(&p.flags[grp], 1u);
+        if (tid == 0) uncounted_flag_store(&p.flags[grp], p.epoch);
     }
+}
+
+// Number of CUs of the current device (the persistent grid is sized from it, not from a constant).
+static int sk_device_cus() {
+#if CLSLAM_DEVICE_BUILD
+    static thread_local int cached_dev = -1, cached_cus = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (dev != cached_dev) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cached_dev = dev; cached_cus = n;
+    }
+    return cached_cus;
+#else
+    return 256;
+#endif
+}
+
+// Per-workspace launch epoch: consecutive launches on a stream publish different flag values (never 0).  Inside a
+// hipGraph capture the argument is frozen, i.e. every replay uses the same value -- the consumer's reset to 0 keeps
+// that case working exactly like a 0/1 flag.
+static unsigned sk_next_epoch(const void* workspace) {
+    static std::mutex mu;
+    static std::unordered_map<const void*, unsigned> epochs;
+    std::lock_guard<std::mutex> lock(mu);
+    unsigned& e = epochs[workspace];
+    e = e == 0xFFFFFFFFu ? 1u : e + 1u;
+    return e;
 }
 
 template <int TH, int TW, bool RUN, int S, int BN, int NWM, int NWN>
@@ -425,7 +460,8 @@ static int launch_sk(SkK k, const clslam_conv_desc* d, hipStream_t stream) {
     constexpr int PPs = RUN ? sk_run_pp(BM) : (PHs * PWs + 15) / 16 * 16;
     constexpr size_t lds_bytes = (size_t)2 * (PPs + 9 * BN) * 64 + 16;
     constexpr int per_cu = (int)std::max<size_t>(1, std::min<size_t>((size_t)(163840 / lds_bytes), (size_t)(2048 / (NWM * NWN * 64))));
-    int G = 256 * per_cu;
+    // (every workgroup must be co-resident: a consumer spins on lower-indexed producers; per_cu is the LDS / thread limit)
+    int G = sk_device_cus() * per_cu;
     if (const char* e = getenv("CLSLAM_SK_GROUPS")) G = std::max(1, atoi(e));
     G = (int)std::min<long long>(std::min(G, kSkMaxGroups), k.units);
     k.G = G;
@@ -435,6 +471,7 @@ static int launch_sk(SkK k, const clslam_conv_desc* d, hipStream_t stream) {
         return CLSLAM_ERR_INVALID;
     }
     k.flags = (unsigned*)d->workspace + kSkFlagOffset;
+    k.epoch = sk_next_epoch(d->workspace);
     k.slabs = (float*)((char*)d->workspace + kSkSlabOffsetBytes);
     auto kern = conv3x3_sk_kernel<TH, TW, RUN, S, BN, NWM, NWN>;
 #if CLSLAM_DEVICE_BUILD
@@ -458,6 +495,7 @@ int conv3x3_sk_dispatch(const clslam_conv_desc* d, int cfg, hipStream_t stream) 
     k.B = d->batch; k.Hi = d->in_h; k.Wi = d->in_w; k.Ca = d->ch_a; k.Cb = d->ch_b; k.Ho = d->out_h; k.Wo = d->out_w;
     k.Cout = d->ch_out; k.pad = d->pad; k.pad_mode = d->pad_mode; k.ups = d->upsample_a; k.act = d->act;
     k.tilesX = k.tilesY = k.tilesN = k.tiles = k.NC = k.G = 0; k.units = 0; k.slabs = nullptr; k.flags = nullptr;
+    k.epoch = 1u;
     k.dbg = 0;
     if (const char* e = getenv("CLSLAM_SK_DBG")) k.dbg = atoi(e);
     const bool s2 = st == 2;

@@ -100,7 +100,7 @@ class EngineAdam(optim.Adam):
 
 class DepthPosePrediction:
     def __init__(self, dataset_config, config: Config, use_online: bool = False, reference_quirks: bool = True,
-                 host_pose_output: Optional[bool] = None):
+                 host_pose_output: Optional[bool] = None, upload_all_inputs: Optional[bool] = None):
         # Initialize parameters (dpp.py:41-68) ===========
         self.config_file = config.config_file
         self.dataset_type = dataset_config.dataset
@@ -225,18 +225,25 @@ class DepthPosePrediction:
         self._loss_host = None   # pinned 18-float staging buffer + event: the step's loss scalars (NaN check, return value)
         self._loss_event = None
         self._mode = None
-        # host -> device upload of a minibatch (dpp.py:916-917): only the tensors the path reads, on a copy stream,
-        # network inputs first -- the encoders start while the loss-stage images are still crossing PCIe
-        self.upload_all_inputs = os.environ.get('CLSLAM_UPLOAD_ALL', '0') == '1'
+        # host -> device upload of a minibatch (dpp.py:916-917): EVERY tensor of the caller's dict is moved in place like the
+        # reference does, on a copy stream, in the order the step needs them: the three network inputs first (the encoders
+        # start while the rest is still crossing PCIe), then the ten other entries the path reads, then the entries it does not
+        # read (15 of the 24 image planes, poses, ...), which nothing on the step waits for.  upload_all_inputs=False /
+        # CLSLAM_UPLOAD_ALL=0 leaves those on the host (a deviation from dpp.py:916-917: opt-in).
+        if upload_all_inputs is None:
+            upload_all_inputs = os.environ.get('CLSLAM_UPLOAD_ALL', '1') != '0'
+        self.upload_all_inputs = bool(upload_all_inputs)
         self._copy_stream = None
-        # adapt(online, training) hands out outputs['cam_T_cam', 0, +-1] as HOST tensors (staged with the loss scalars behind
-        # the forward, before the backward is enqueued).  The caller reads exactly these back after every frame
-        # (slam.py:181-186: `[0, :]`, linalg.inv, `.cpu()`): on device tensors that `.cpu()` is ordered behind the whole
-        # backward + optimizer step on the stream, so the host -- and with it the next frame's upload and forward launches --
-        # stood still for the rest of the step (0.37 ms of an end-to-end frame at B = 5).  host_pose_output=False /
-        # CLSLAM_HOST_POSE=0 returns device tensors like the reference.
+        # Opt-in fast path (host_pose_output=True / CLSLAM_HOST_POSE=1): adapt(online, training) hands out
+        # outputs['cam_T_cam', 0, +-1] AND the loss dict as HOST tensors, staged behind the forward before the backward is
+        # enqueued (the loss scalars are staged in any case for the NaN check of dpp.py:1115-1118).  The SLAM driver reads
+        # exactly these back after every frame (slam.py:181-188: `[0, :]`, linalg.inv, `.cpu()` per key): on device tensors
+        # the first `.cpu()` is ordered behind the whole backward + optimizer step on the stream, so the host -- and with it
+        # the next frame's upload and forward launches -- stands still for the rest of the step (0.37 ms of an end-to-end
+        # frame at B = 5).  The DEFAULT is the reference's behaviour: every output and every loss is a device tensor in all
+        # three modes (training adapt, adapt(online, None), predict()).
         if host_pose_output is None:
-            host_pose_output = os.environ.get('CLSLAM_HOST_POSE', '1') != '0'
+            host_pose_output = os.environ.get('CLSLAM_HOST_POSE', '0') == '1'
         self.host_pose_output = bool(host_pose_output)
         self._pose_host: Dict[int, Tensor] = {}
         self._pose_staged = None
@@ -255,6 +262,7 @@ class DepthPosePrediction:
         self._dp = dict(group=process_group, global_batch=int(global_batch_size), offset=int(shard_offset), dist=dist)
         # overlap the gradient all-reduce + Adam with the next step's (frozen) encoders
         self.engine.async_tail = os.environ.get('CLSLAM_ASYNC_TAIL', '1') != '0'
+        self.engine.noise_stream = int(shard_offset)     # identically seeded ranks draw different tie-break fields
 
     def gather_outputs(self, outputs: Dict[Any, Tensor]) -> Dict[Any, Tensor]:
         """Data-parallel mode: every rank's `outputs` shard concatenated in rank (= sample) order on every
@@ -360,6 +368,8 @@ class DepthPosePrediction:
                 self.optimizer.loss_guard = None
                 losses = self._staged_losses()
                 self._raise_on_nan(losses, undo_step=True)
+                if not self.host_pose_output:        # reference behaviour: the loss dict lives on the device
+                    losses = self.engine.losses_dict(self._losses_dev)
             if self._pose_staged is not None:
                 # the event _staged_losses() waited for covers the pose copy issued just before the loss copy
                 T = self._pose_host[self._pose_staged].clone()
@@ -539,14 +549,15 @@ class DepthPosePrediction:
                    ('rgb', -1, 0), ('rgb', 1, 0), ('rgb', 0, 0), ('rgb', 0, 1), ('rgb', 0, 2), ('rgb', 0, 3)]
 
     def _upload(self, inputs: Dict[Any, Tensor]):
-        """Move the caller's dict to the device in place like dpp.py:916-917 -- but only the 13 entries the path reads
-        (9 image planes of 24; CLSLAM_UPLOAD_ALL=1 / upload_all_inputs moves every entry like the reference), and
-        asynchronously: the copies run on their own stream (pinned sources: DataLoader(pin_memory=True), slam.py:86),
-        the three network inputs first.  Returns the events (rgb_aug[0] there, rgb_aug[-1] there, rgb_aug[+1] there,
-        everything there) for the engine's streams to wait on, or None when nothing had to move."""
+        """Move the caller's dict to the device in place like dpp.py:916-917, asynchronously: the copies run on their own
+        stream (pinned sources: DataLoader(pin_memory=True), slam.py:86), the three network inputs first, then the ten
+        other entries the path reads, then everything else (upload_all_inputs=False: left on the host).  Returns the
+        events (rgb_aug[0] there, rgb_aug[-1] there, rgb_aug[+1] there, everything the path reads there, the whole dict
+        there) for the engine's streams / the caller's stream to wait on, or None when nothing had to move."""
         dev = self.device
         todo = [k for k in self.UPLOAD_FIRST + self.UPLOAD_REST if k in inputs and inputs[k].device != dev]
-        extra = [k for k in inputs if self.upload_all_inputs and k not in self.UPLOAD_FIRST + self.UPLOAD_REST
+        known = set(self.UPLOAD_FIRST + self.UPLOAD_REST)
+        extra = [k for k in inputs if self.upload_all_inputs and k not in known
                  and isinstance(inputs[k], Tensor) and inputs[k].device != dev]
         if not todo and not extra:
             return None
@@ -576,12 +587,18 @@ class DepthPosePrediction:
                 ev = torch.cuda.Event()
                 ev.record(cs)
                 evs.append(ev)
-            for k in todo + extra:
+            for k in todo:
                 if k not in self.UPLOAD_FIRST:
                     copy(k)
             all_ev = torch.cuda.Event()
             all_ev.record(cs)
-        return evs[0], evs[1], evs[2], all_ev
+            dict_ev = all_ev
+            if extra:                        # not read by the step: only the caller's stream is ordered behind them
+                for k in extra:
+                    copy(k)
+                dict_ev = torch.cuda.Event()
+                dict_ev.record(cs)
+        return evs[0], evs[1], evs[2], all_ev, dict_ev
 
     def _process_batch(self, inputs: Dict[Any, Tensor], loss_sample_weights: Optional[Tensor] = None,
                        use_online: bool = False, train: bool = False, graphed: bool = False, copy_inputs: bool = True,
@@ -600,6 +617,9 @@ class DepthPosePrediction:
         else:
             outputs, losses = self.engine.forward(inputs, train=train, sample_w=sample_w, smooth_w=smooth_w,
                                                   noise=self._injected_noise, reuse_frozen=reuse_frozen, inputs_ready=ready)
+        if ready is not None and ready[4] is not ready[3]:
+            # the caller's dict is device-resident from its stream's point of view when the call returns (dpp.py:916-917)
+            torch.cuda.current_stream(self.device).wait_event(ready[4])
         if self._dp is not None and train:
             # only training steps are collective: predict() / adapt(online, None) on one rank (slam.py:178 on the
             # rank that holds the online frame) must not pair up with another rank's gradient exchange
@@ -623,6 +643,8 @@ class DepthPosePrediction:
                 self._loss_event.synchronize()
                 loss_dict = self.engine.losses_dict(self._loss_host.clone())
                 self._raise_on_nan(loss_dict)
+                if not self.host_pose_output:
+                    loss_dict = self.engine.losses_dict(losses)
             else:
                 loss_dict = None         # adapt() builds it after the optimizer launch (see there)
         else:

@@ -19,11 +19,12 @@ def make_config(B, log_path='/tmp/clslam_test_log', **over):
     return Config(**kw)
 
 
-def make_predictor(H, W, B, seed=0, reference_quirks=True, host_pose_output=None, **over):
+def make_predictor(H, W, B, seed=0, reference_quirks=True, host_pose_output=None, upload_all_inputs=None, **over):
     from depth_pose_prediction import DepthPosePrediction
     ds = SimpleNamespace(dataset='Kitti', config_file=Path('x.yaml'), dataset_path=None, scales=(0, 1, 2, 3), height=H,
                          width=W, frame_ids=(0, -1, 1))
-    p = DepthPosePrediction(ds, make_config(B, **over), reference_quirks=reference_quirks, host_pose_output=host_pose_output)
+    p = DepthPosePrediction(ds, make_config(B, **over), reference_quirks=reference_quirks, host_pose_output=host_pose_output,
+                            upload_all_inputs=upload_all_inputs)
     for name, m in p.models.items():
         sd = torch.nn.Module.state_dict(m)
         m.load_state_dict(synth.fill_state_dict(sd, seed, name))

@@ -89,3 +89,41 @@ def test_inference_replica_follows_the_trainer(tmp_path):
     p.set_tie_break_noise(synth.make_noise(1, H, W, seed=100 + rec['frame']))
     out, _ = p.adapt(synth.make_batch(1, H, W, seed=60 + rec['frame']), None)
     assert torch.equal(out['depth', 0], rec['depth']) and torch.equal(out['cam_T_cam', 0, 1], rec['T'])
+
+
+def _abort_worker(rank, world, port, out_dir):
+    for p in (ROOT / 'cl-slam_amd', ROOT, ROOT / 'tests'):
+        sys.path.insert(0, str(p))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), CLSLAM_EMU_THREADS='4')
+    torch.set_num_threads(2)
+    import torch.distributed as dist
+    from clslam_hip import synth
+    from clslam_hip.async_mode import AsyncAdaptation
+    from emu_util import use_backend
+    from predictor_util import make_predictor
+    use_backend('emu')
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    p = make_predictor(H, W, 1)
+    am = AsyncAdaptation(p, sync_every=1, transfer_timeout_s=300.0)
+    what = 'finished'
+    try:
+        for f in range(2):
+            online = synth.make_batch(1, H, W, seed=60 + f)
+            if rank == 1 and f == 1:            # the trainer's second step fails like dpp.py:1115-1118
+                online['relative_distance', 0] = torch.full_like(online['relative_distance', 0], float('nan'))
+            am.step(f, online, online if rank == 1 else None)
+        am.flush()
+    except RuntimeError as e:
+        what = str(e)
+    (Path(out_dir) / f'rank{rank}.txt').write_text(what)
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(1200)
+def test_failed_trainer_releases_the_inference_replica(tmp_path):
+    """A trainer whose step raises (NaN loss) posts an abort marker instead of its snapshot: the inference replica, which
+    would otherwise wait for that broadcast forever, raises too."""
+    port = 29500 + (os.getpid() % 2000) + 11
+    mp.start_processes(_abort_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True, start_method='spawn')
+    assert 'NaN loss' in (tmp_path / 'rank1.txt').read_text()
+    assert 'training replica failed' in (tmp_path / 'rank0.txt').read_text()

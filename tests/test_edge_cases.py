@@ -118,3 +118,43 @@ def test_launch_on_steers_launches_and_restores_on_error():
         with ops.launch_on(FakeStream(33)):
             raise ValueError('boom')
     assert ops._FORCED_STREAM is None and ops._stream(t) == 0
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_tie_break_noise_follows_torch_manual_seed(backend):
+    """dpp.py:1055-1056 draws from torch's global generator: a torch.manual_seed() at any time re-seeds it.  The in-kernel
+    Philox stream is keyed by the device generator's seed on every forward (not frozen at construction), restarts its
+    draw counter on a re-seed, and data-parallel ranks (engine.noise_stream = shard offset) draw different fields from
+    the same seed.  Two predictors seeded alike run bitwise the same adaptation step."""
+    use_backend(backend)
+    from clslam_hip import synth
+    from predictor_util import make_predictor
+    H, W, B = 64, 128, 1
+    p = make_predictor(H, W, B)
+    e = p.engine
+    torch.manual_seed(5)
+    a1, a2 = e._next_noise_draw(), e._next_noise_draw()
+    assert a1[0] == a2[0] and a2[1] == a1[1] + 1
+    if backend == 'hip':                                   # the draw counter is the device generator's Philox offset
+        torch.manual_seed(5)
+        assert e._next_noise_draw() == a1                  # re-seeding AFTER construction reproduces the stream
+        state = torch.cuda.get_rng_state()
+        nxt = e._next_noise_draw()
+        torch.cuda.set_rng_state(state)
+        assert e._next_noise_draw() == nxt
+    torch.manual_seed(6)
+    c1 = e._next_noise_draw()
+    assert c1[0] != a1[0] and c1[1] == a1[1]
+    e.noise_stream = 3
+    torch.manual_seed(5)
+    d1 = e._next_noise_draw()
+    assert d1[0] == a1[0] and d1[1] != a1[1] and (d1[1] & 0xFFFFFFFFFF) == a1[1]
+    e.noise_stream = 0
+    batch = synth.make_batch(B, H, W, seed=12)
+    res = []
+    for seed in (7, 7, 8):
+        q = make_predictor(H, W, B)
+        torch.manual_seed(seed)
+        _, losses = q.adapt(None, {k: v.clone() for k, v in batch.items()}, steps=2)
+        res.append((q.engine.w.clone(), float(losses['loss'])))
+    assert torch.equal(res[0][0], res[1][0]) and res[0][1] == res[1][1]

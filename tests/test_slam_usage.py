@@ -205,38 +205,50 @@ def test_uniform_random_image_content_matches_oracle(backend):
 
 
 @pytest.mark.gpu
-def test_host_batch_upload_is_selective_asynchronous_and_invisible():
-    """adapt() on a pinned HOST minibatch (slam.py hands over DataLoader output): only the 13 entries the path reads are
-    moved to the device (dpp.py:916-917 moves all 35), on a copy stream with the network inputs first -- and the step is
-    bitwise the one computed from a minibatch already resident in HBM; the loss dict comes back on the host."""
+@pytest.mark.parametrize('upload_all', [True, False])
+def test_host_batch_upload_is_asynchronous_and_invisible(upload_all):
+    """adapt() on a pinned HOST minibatch (slam.py hands over DataLoader output).  Default: EVERY entry of the caller's
+    dict is moved to the device in place like dpp.py:916-917 -- on a copy stream, network inputs first, the entries the
+    path never reads last (nothing of the step waits for them; the caller's stream is ordered behind them when the call
+    returns).  upload_all_inputs=False (opt-in): only the 13 entries the path reads move.  Either way the step is bitwise
+    the one computed from a minibatch already resident in HBM."""
     use_backend('hip')
     B = 3
     batch = synth.make_batch(B, H, W, seed=51)
     noise = {s: v.cuda() for s, v in synth.make_noise(B, H, W, seed=52).items()}
     results = []
     for mode in ('device', 'host'):
-        p = make_predictor(H, W, B)
+        p = make_predictor(H, W, B, upload_all_inputs=upload_all)
         p.set_tie_break_noise(noise)
         feed = {k: (v.cuda() if mode == 'device' else v.clone().pin_memory()) for k, v in batch.items()}
         for _ in range(2):                       # twice: the second call re-uploads into recycled blocks
             moved = dict(feed) if mode == 'host' else feed
             out, losses = p.adapt(None, moved, steps=1)
+            if mode == 'host':                   # stream-ordered use of a never-read entry right after the call returns
+                probe = moved['rgb_aug', 0, 3] if upload_all else None
+                if probe is not None:
+                    assert probe.is_cuda and torch.equal(probe.cpu(), batch['rgb_aug', 0, 3])
         torch.cuda.synchronize()
         if mode == 'host':
-            on_dev = sorted(str(k) for k, v in moved.items() if v.is_cuda)
-            assert len(on_dev) == 13 and all(k in moved and moved[k].is_cuda for k in p.UPLOAD_FIRST + p.UPLOAD_REST)
-            assert not moved['rgb', -1, 2].is_cuda and not moved['rgb_aug', 0, 3].is_cuda      # never read: left alone
-        assert all(not v.is_cuda for v in losses.values())                                     # one D2H per step
+            assert all(moved[k].is_cuda for k in p.UPLOAD_FIRST + p.UPLOAD_REST)
+            if upload_all:
+                assert all(v.is_cuda for v in moved.values())                                   # dpp.py:916-917
+                for k, v in moved.items():
+                    assert torch.equal(v.cpu(), batch[k]), k
+            else:
+                assert sum(v.is_cuda for v in moved.values()) == 13
+                assert not moved['rgb', -1, 2].is_cuda and not moved['rgb_aug', 0, 3].is_cuda  # never read: left alone
+        assert all(v.is_cuda for v in losses.values())                                         # reference: device tensors
         results.append((out['depth', 0].clone(), out['cam_T_cam', 0, 1].clone(), float(losses['loss']), p.engine.w.clone()))
     for a, b in zip(results[0], results[1]):
         assert (a == b) if isinstance(a, float) else torch.equal(a, b)
 
 
 @pytest.mark.gpu
-def test_pose_is_handed_out_on_the_host_without_waiting_for_the_backward():
-    """adapt(online, training) returns outputs['cam_T_cam', 0, +-1] as host tensors staged behind the forward (what
-    slam.py:181-186 reads back every frame): bitwise the device result of host_pose_output=False, and reading them does not
-    wait for the backward + optimizer step still running on the stream."""
+def test_host_outputs_fast_path_is_opt_in_and_bitwise_the_device_result():
+    """Opt-in host_pose_output=True: adapt(online, training) returns outputs['cam_T_cam', 0, +-1] and the loss dict as
+    host tensors staged behind the forward (what slam.py:181-188 reads back every frame) -- bitwise the device result of
+    the default, and reading them does not wait for the backward + optimizer step still running on the stream."""
     use_backend('hip')
     B = 3
     batch = {k: v.cuda() for k, v in synth.make_batch(B, H, W, seed=61).items()}
@@ -245,17 +257,57 @@ def test_pose_is_handed_out_on_the_host_without_waiting_for_the_backward():
     for host in (True, False):
         p = make_predictor(H, W, B, host_pose_output=host)
         p.set_tie_break_noise(noise)
-        out, _ = p.adapt(None, dict(batch), steps=2)
+        out, losses = p.adapt(None, dict(batch), steps=2)
         for f in (-1, 1):
             assert out['cam_T_cam', 0, f].is_cuda == (not host) and tuple(out['cam_T_cam', 0, f].shape) == (B, 4, 4)
+        assert all(v.is_cuda == (not host) for v in losses.values())
         # what slam.py does with it
         T = torch.linalg.inv(out['cam_T_cam', 0, 1][0, :]).squeeze().cpu().detach().numpy()
         assert T.shape == (4, 4)
-        got[host] = [out['cam_T_cam', 0, f].cpu().clone() for f in (-1, 1)]
+        got[host] = [out['cam_T_cam', 0, f].cpu().clone() for f in (-1, 1)] + [losses[k].cpu().clone() for k in sorted(losses)]
         torch.cuda.synchronize()
     for a, b in zip(got[True], got[False]):
         assert torch.equal(a, b)
-    # predict() / adapt(online, None) keep device tensors (their callers feed them back into device code)
+
+
+@pytest.mark.gpu
+def test_default_outputs_live_on_one_device_in_all_three_modes():
+    """The boundary the reference's callers rely on (dpp.py:916-923: everything `_process_batch` returns sits on
+    self.device): a caller that feeds outputs['cam_T_cam', 0, f] into device math together with outputs['depth', 0] --
+    re-projecting the predicted depth with the predicted pose, T @ K -- works after a training adapt(), after
+    adapt(online, None) and after predict() without a device mismatch.  With the opt-in host fast path the same code
+    raises for the training call only: that divergence is why it is not the default."""
+    use_backend('hip')
+    B = 2
+    batch = {k: v.cuda() for k, v in synth.make_batch(B, H, W, seed=71).items()}
+
+    def caller_math(out, inputs):
+        T = out['cam_T_cam', 0, 1]
+        K = inputs['camera_matrix', 0]
+        depth = out['depth', 0]
+        P = (K @ T)[:, :3, :]                                           # (B,3,4) on the device
+        pix = torch.stack([torch.full_like(depth[:, 0], 10.0), torch.full_like(depth[:, 0], 7.0), torch.ones_like(depth[:, 0])], 1)
+        cam = (inputs['inv_camera_matrix', 0][:, :3, :3] @ pix.flatten(2)) * depth.flatten(2)
+        cam = torch.cat([cam, torch.ones_like(cam[:, :1])], 1)
+        return (P @ cam).sum() + sum(v.sum() for v in (out['axis_angle', 0, 1], out['translation', 0, -1]))
+
     p = make_predictor(H, W, B)
-    out, _ = p.adapt(dict(batch), None)
-    assert out['cam_T_cam', 0, 1].is_cuda
+    for mode in ('train', 'eval', 'predict'):
+        feed = dict(batch)
+        if mode == 'train':
+            out, losses = p.adapt(None, feed, steps=1)
+        elif mode == 'eval':
+            out, losses = p.adapt(feed, None)
+        else:
+            out, losses = p.predict(feed), None
+        assert all(v.device == p.device for v in out.values()), mode
+        if losses is not None:
+            assert all(v.device == p.device for v in losses.values()), mode
+            assert torch.isfinite(losses['loss'] + out['depth', 0].mean())      # (1,) device loss + device tensor
+        assert torch.isfinite(caller_math(out, feed))
+    fast = make_predictor(H, W, B, host_pose_output=True)
+    out, _ = fast.adapt(None, dict(batch), steps=1)
+    with pytest.raises(RuntimeError, match='device'):
+        caller_math(out, batch)
+    out, _ = fast.adapt(dict(batch), None)                                      # forward-only calls: device tensors
+    assert torch.isfinite(caller_math(out, batch))
