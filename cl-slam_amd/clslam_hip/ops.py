@@ -466,6 +466,14 @@ def warp_fwd_pyramid(disps, src_m1, src_p1, inv_k, proj, depth, warped, min_dept
                         _p(warped), B, H, W, _nd(min_depth), _nd(max_depth), _stream(depth))
 
 
+def warp_cells_pyramid(disps, inv_k, proj, cells, min_depth, max_depth):
+    """diagnostic: cells (4,2,B,H,W) int32 = x0 | y0 << 12 | (x not clipped) << 24 | (y not clipped) << 25"""
+    B, H, W = cells.shape[2], cells.shape[-2], cells.shape[-1]
+    _lib.get_lib().call('clslam_warp_cells_pyramid', _ptr4(disps), _p(inv_k), _p(proj), _pa(cells, torch.int32), B, H, W,
+                        _nd(min_depth), _nd(max_depth), _stream(cells))
+    return cells
+
+
 def automask_pyramid(idmap, noise, rpmap, sel, partial, batch, H, W):
     _lib.get_lib().call('clslam_automask_pyramid', _p(idmap), _p(noise), _p(rpmap), _pa(sel, torch.uint8), _p(partial), 4,
                         batch, H, W, _stream(idmap))

@@ -353,6 +353,55 @@ extern "C" int clslam_warp_fwd_pyramid(const float* const* disp, const float* sr
     return check_launch("warp_fwd_pyramid");
 }
 
+// Diagnostic twin of warp_fwd_kernel (tests/test_backward_parity.py): the bilinear CELL and the border-clip flags the
+// path uses for every (scale, source frame, sample, pixel), packed as x0 | y0 << 12 | (mx != 0) << 24 | (my != 0) << 25.
+// The same expressions, in the same order, as warp_fwd_kernel / the loss backward: the oracle is re-run on exactly these
+// cells to attribute the part of the gradient residual that comes from samples landing on the other side of a kink.
+__global__ __launch_bounds__(256) void warp_cells_kernel(Pyramid pyr, const float* __restrict__ Kinv,
+                                                         const float* __restrict__ P, int* __restrict__ cells, int B, int H,
+                                                         int W, float da, float db, int dmode, int tilesX) {
+    const int b = blockIdx.y, sc = blockIdx.z;
+    const int ty = blockIdx.x / tilesX, tx = blockIdx.x - ty * tilesX;
+    const int x = tx * WF_TW + (int)(threadIdx.x & 63), y = ty * WF_TH + (int)(threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    const unsigned HW = (unsigned)(H * W);
+    const unsigned pix = __umul24((unsigned)y, (unsigned)W) + (unsigned)x;
+    const int h = pyr.h[sc], w = pyr.w[sc];
+    const float disp = upsample_disp(pyr.disp[sc] + (size_t)b * h * w, h, w, H, W, y, x);
+    const float dep = disp_to_depth_dev(disp, da, db, dmode);
+    const float* Ki = Kinv + (size_t)b * 16;
+    const float fx = (float)x, fy = (float)y;
+    float X[3];
+    for (int i = 0; i < 3; ++i) X[i] = dep * (Ki[i * 4 + 0] * fx + Ki[i * 4 + 1] * fy + Ki[i * 4 + 2]);
+#pragma unroll
+    for (int fi = 0; fi < 2; ++fi) {
+        const float* Pm = P + ((size_t)fi * B + b) * 12;
+        float p[3];
+        for (int i = 0; i < 3; ++i) p[i] = Pm[i * 4 + 0] * X[0] + Pm[i * 4 + 1] * X[1] + Pm[i * 4 + 2] * X[2] + Pm[i * 4 + 3];
+        const float den = p[2] + 1e-7f;
+        const Sample s = sample_coords(p[0] / den, p[1] / den, H, W);
+        (cells + (((size_t)sc * 2 + fi) * B + b) * HW)[pix] =
+            s.x0 | (s.y0 << 12) | ((s.mx != 0.f ? 1 : 0) << 24) | ((s.my != 0.f ? 1 : 0) << 25);
+    }
+}
+
+extern "C" int clslam_warp_cells_pyramid(const float* const* disp, const float* inv_k, const float* proj, int* cells, int batch,
+                                         int H, int W, float min_depth, float max_depth, void* stream) {
+    CLSLAM_REQUIRE(disp && inv_k && proj && cells, "warp_cells_pyramid: null");
+    CLSLAM_REQUIRE(!(min_depth <= 0.f && max_depth > 0.f), "warp_cells_pyramid: min_depth is None");
+    CLSLAM_REQUIRE(H < 4096 && W < 4096, "warp_cells_pyramid: image too large for the packed cell format");
+    float a, b; int mode;
+    depth_mode(min_depth, max_depth, &a, &b, &mode);
+    Pyramid pyr;
+    pyr.n = 4;
+    for (int k = 0; k < 4; ++k) { pyr.disp[k] = disp[k]; pyr.h[k] = H >> k; pyr.w[k] = W >> k; }
+    if (!batch) return CLSLAM_OK;
+    const int tilesX = cdiv(W, WF_TW);
+    hipLaunchKernelGGL(warp_cells_kernel, dim3(tilesX * cdiv(H, WF_TH), batch, 4), dim3(256), 0, (hipStream_t)stream, pyr, inv_k,
+                       proj, cells, batch, H, W, a, b, mode, tilesX);
+    return check_launch("warp_cells_pyramid");
+}
+
 extern "C" int clslam_warp_bwd_blocks(int H, int W) { return std::max(1, std::min(256, cdiv(H * W, 1024))); }
 
 extern "C" int clslam_warp_bwd(const float* dpred, const float* disp_s, int h, int w, const float* src_m1,

@@ -182,6 +182,11 @@ int clslam_warp_fwd(const float* disp_s, int h, int w, const float* src_m1, cons
 int clslam_warp_fwd_pyramid(const float* const* disp, const float* src_m1, const float* src_p1, const float* inv_k,
                             const float* proj, float* depth, float* warped, int batch, int H, int W, float min_depth,
                             float max_depth, void* stream);
+/* Diagnostic (parity tests): the bilinear cell and border-clip flags the path uses per (scale, source frame, sample,
+ * pixel) -- what F.grid_sample decides internally at dpp.py:1013-1017.  cells (4,2,B,H,W) int32 =
+ * x0 | y0 << 12 | (x not clipped) << 24 | (y not clipped) << 25; same arguments as clslam_warp_fwd_pyramid.          */
+int clslam_warp_cells_pyramid(const float* const* disp, const float* inv_k, const float* proj, int* cells, int batch, int H,
+                              int W, float min_depth, float max_depth, void* stream);
 int clslam_warp_bwd_blocks(int H, int W);
 /* ddisp_up (B,H,W) = dL/d(upsampled disparity); dp_partial [B][nblk][24] block sums of dL/dproj */
 int clslam_warp_bwd(const float* dpred, const float* disp_s, int h, int w, const float* src_m1, const float* src_p1,

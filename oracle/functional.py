@@ -98,18 +98,68 @@ def project(points: Tensor, K: Tensor, T: Tensor, H: int, W: int, eps: float = 1
     return (pix - 0.5) * 2
 
 
+def grid_sample_border(src: Tensor, grid: Tensor, cells=None, record=None) -> Tensor:
+    """F.grid_sample(src, grid, mode='bilinear', padding_mode='border', align_corners=True) (dpp.py:1013-1017) written
+    out the way ATen's grid sampler computes it: un-normalise, clip to the image with the gradient
+    zeroed at / outside the border (clip_coordinates_set_grad), floor, four taps weighted by the opposite corner's
+    distance, taps beyond the last row / column dropped.  tests/test_oracle_golden.py holds it to F.grid_sample in value
+    and gradient.
+
+    The function is piecewise smooth in the sampling position: which CELL (x0, y0) a sample falls into and whether it is
+    CLIPPED are decisions, and two implementations whose positions differ by 1e-5 px take them differently for a few
+    pixels.  `cells = (x0, y0, mx, my)` (LongTensor x2, BoolTensor x2, each (B,H,W)) imposes another implementation's
+    decisions -- the kernel path's, tests/test_backward_parity.py -- the way `forced_sel` imposes its 4-way-min selection;
+    `record` (a list) receives this call's own decisions."""
+    B, C, H, W = src.shape
+    ix = ((grid[..., 0] + 1) / 2) * (W - 1)
+    iy = ((grid[..., 1] + 1) / 2) * (H - 1)
+    if cells is None:
+        mx = (ix > 0) & (ix < W - 1)
+        my = (iy > 0) & (iy < H - 1)
+        x0 = torch.floor(ix.detach().clamp(0, W - 1)).long()
+        y0 = torch.floor(iy.detach().clamp(0, H - 1)).long()
+    else:
+        x0, y0, mx, my = cells
+    if record is not None:
+        record.append((x0, y0, mx, my))
+    ixc = torch.where(mx, ix, ix.detach().clamp(0, W - 1))      # clipped coordinate; no gradient where clipped
+    iyc = torch.where(my, iy, iy.detach().clamp(0, H - 1))
+    wx1, wy1 = ixc - x0.to(ix.dtype), iyc - y0.to(iy.dtype)
+    wx0, wy0 = (x0 + 1).to(ix.dtype) - ixc, (y0 + 1).to(iy.dtype) - iyc
+    x1ok, y1ok = (x0 + 1 <= W - 1), (y0 + 1 <= H - 1)
+    x1, y1 = (x0 + 1).clamp(max=W - 1), (y0 + 1).clamp(max=H - 1)
+    flat = src.reshape(B, C, H * W)
+
+    def tap(yy, xx):
+        idx = (yy * W + xx).reshape(B, 1, H_out * W_out).expand(B, C, H_out * W_out)
+        return torch.gather(flat, 2, idx).reshape(B, C, H_out, W_out)
+    H_out, W_out = grid.shape[1], grid.shape[2]
+    zero = torch.zeros((), dtype=src.dtype)
+    out = tap(y0, x0) * (wx0 * wy0).unsqueeze(1)
+    out = out + tap(y0, x1) * torch.where(x1ok, wx1 * wy0, zero).unsqueeze(1)
+    out = out + tap(y1, x0) * torch.where(y1ok, wx0 * wy1, zero).unsqueeze(1)
+    out = out + tap(y1, x1) * torch.where(x1ok & y1ok, wx1 * wy1, zero).unsqueeze(1)
+    return out
+
+
 def reconstruct(disp_s: Tensor, T: Dict[int, Tensor], K: Tensor, inv_K: Tensor,
-                src: Dict[int, Tensor], H: int, W: int, min_depth, max_depth
-                ) -> Tuple[Tensor, Dict[int, Tensor]]:
+                src: Dict[int, Tensor], H: int, W: int, min_depth, max_depth,
+                cells=None, record=None) -> Tuple[Tensor, Dict[int, Tensor]]:
     """dpp.py:986-1017 for one scale: bilinear-upsample disp, disp->depth, backproject,
-    project with scale-0 intrinsics, grid_sample the un-augmented scale-0 source frame."""
+    project with scale-0 intrinsics, grid_sample the un-augmented scale-0 source frame.
+    cells / record: {frame: ...} test hooks of grid_sample_border (the written-out sampler replaces F.grid_sample
+    whenever one of them is given)."""
     disp = F.interpolate(disp_s, [H, W], mode='bilinear', align_corners=False)
     depth = disp_to_depth(disp, min_depth, max_depth)
     pts = backproject(depth, inv_K)
     warped = {}
     for f in (-1, 1):
         grid = project(pts, K, T[f], H, W)
-        warped[f] = F.grid_sample(src[f], grid, padding_mode='border', align_corners=True)
+        if cells is None and record is None:
+            warped[f] = F.grid_sample(src[f], grid, padding_mode='border', align_corners=True)
+        else:
+            rec = None if record is None else record.setdefault(f, [])
+            warped[f] = grid_sample_border(src[f], grid, None if cells is None else cells[f], rec)
     return depth, warped
 
 

@@ -27,6 +27,9 @@ class OraclePredictor:
         self.reference_quirks = reference_quirks
         self.scales = (0, 1, 2, 3)
         self.forced_sel, self.last_combined, self.last_sel = None, {}, {}
+        # test hooks for the view synthesis (functional.grid_sample_border): forced_cells[s][f] = (x0, y0, mx, my) imposes
+        # the bilinear cell / clip decisions of another implementation; record_cells=True keeps this run's own in last_cells
+        self.forced_cells, self.record_cells, self.last_cells = None, False, {}
         self.frame_ids = (0, -1, 1)
         # dpp.py:129-137 (dict insertion order defines the optimizer's parameter order)
         self.models = {
@@ -75,9 +78,13 @@ class OraclePredictor:
             outputs[('cam_T_cam', 0, f)] = T[f]
         src = {f: inputs[('rgb', f, 0)] for f in (-1, 1)}
         for s in self.scales:  # dpp.py:976-1017
+            rec = {} if self.record_cells else None
             depth, warped = OF.reconstruct(outputs[('disp', s)], T, inputs[('camera_matrix', 0)],
                                            inputs[('inv_camera_matrix', 0)], src, H, W,
-                                           self.min_depth, self.max_depth)
+                                           self.min_depth, self.max_depth,
+                                           cells=None if self.forced_cells is None else self.forced_cells[s], record=rec)
+            if rec is not None:
+                self.last_cells[s] = {f: v[0] for f, v in rec.items()}
             outputs[('depth', s)] = depth
             for f in (-1, 1):
                 outputs[('rgb', f, s)] = warped[f]

@@ -33,3 +33,88 @@ def max_rel(a, b, floor: float = 1e-6) -> float:
     a = torch.as_tensor(np.asarray(a), dtype=torch.float64)
     b = torch.as_tensor(np.asarray(b), dtype=torch.float64)
     return float(((a - b).abs() / b.abs().clamp_min(floor)).max())
+
+
+# ---- attributed backward parity (tests/test_backward_parity.py, tests/test_predictor.py) ---------------------------
+def oracle_grads(o, batch, noise):
+    o.set_adapt()
+    out, losses = o.process_batch(batch, noise, None)
+    o.optimizer.zero_grad()
+    losses['loss'].backward()
+    grads = {}
+    for model in ('depth_decoder', 'pose_decoder'):
+        for k, prm in o.models[model].named_parameters():
+            grads[f'{model}/{k}'] = prm.grad.detach().clone()
+    return out, {k: v.detach() for k, v in losses.items()}, grads
+
+
+def rel_l2(a, b) -> float:
+    return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
+
+
+def attributed_gradient_errors(p, batch, noise, dev):
+    """`p`: the product predictor right after ONE adapt(steps=1) on (batch, noise).  Compares its 36 gradient tensors (full
+    tensors, relative L2) with the oracle's autograd three times: free; with the oracle forced to the kernel path's 4-way-min
+    selection; and with the kernel path's bilinear cells and border-clip flags imposed on the oracle's written-out sampler
+    as well (clslam_warp_cells_pyramid -> oracle.functional.grid_sample_border).  Returns a dict with the flip counts,
+    the rows (name, e_free, e_same_selection, norm, e_same_decisions) and the free oracle's losses / gradients."""
+    import math
+    from clslam_hip import ops
+    from clslam_hip.engine import TrainableLayout
+    eng = p.engine
+    B, H, W = batch['rgb', 0, 0].shape[0], p.height, p.width
+    eng.wait_training()
+    hip = {name: TrainableLayout.to_reference(eng.g[off:off + math.prod(shape)], shape).cpu().clone()
+           for name, off, shape in eng.layout.entries}
+    ws = eng._ws[B]
+    sel_hip = ws.sel.cpu().clone()                       # (4, B, H, W) u8
+    o = make_oracle(H, W, B)
+    _, ol, ref = oracle_grads(o, batch, noise)
+    # (a) selection flips: few, and all of them near-ties
+    flips, worst_gap = 0, 0.0
+    for s in range(4):
+        so, sh = o.last_sel[s], sel_hip[s].long()
+        diff = so != sh
+        flips += int(diff.sum())
+        if diff.any():
+            comb = o.last_combined[s]
+            a = torch.gather(comb, 1, so.unsqueeze(1)).squeeze(1)[diff]
+            b = torch.gather(comb, 1, sh.unsqueeze(1)).squeeze(1)[diff]
+            worst_gap = max(worst_gap, float((b - a).abs().max()))
+    # (b) the oracle on the kernel path's selection
+    o2 = make_oracle(H, W, B)
+    o2.forced_sel = {s: sel_hip[s] for s in range(4)}
+    o2.record_cells = True
+    _, _, forced = oracle_grads(o2, batch, noise)
+    # (c) ... and on the kernel path's bilinear cells / clip flags as well
+    cells = torch.empty(4, 2, B, H, W, dtype=torch.int32, device=dev)
+    ops.warp_cells_pyramid(ws.disp, ws.ctx.Kinv, ws.P, cells, p.min_depth, p.max_depth)
+    cells = cells.cpu()
+    forced_cells, cell_flips, clip_flips = {}, 0, 0
+    for s in range(4):
+        forced_cells[s] = {}
+        for fi, f in enumerate((-1, 1)):
+            c = cells[s, fi].long()
+            mine = ((c & 0xFFF), ((c >> 12) & 0xFFF), ((c >> 24) & 1).bool(), ((c >> 25) & 1).bool())
+            forced_cells[s][f] = mine
+            theirs = o2.last_cells[s][f]
+            cell_flips += int(((mine[0] != theirs[0]) | (mine[1] != theirs[1])).sum())
+            clip_flips += int(((mine[2] != theirs[2]) | (mine[3] != theirs[3])).sum())
+    o3 = make_oracle(H, W, B)
+    o3.forced_sel = {s: sel_hip[s] for s in range(4)}
+    o3.forced_cells = forced_cells
+    _, _, forced3 = oracle_grads(o3, batch, noise)
+    rows = [(name, rel_l2(hip[name], ref[name]), rel_l2(hip[name], forced[name]), float(ref[name].norm()),
+             rel_l2(hip[name], forced3[name])) for name in hip]
+    return dict(flips=flips, npix=4 * B * H * W, gap=worst_gap, rows=rows, cell_flips=cell_flips, clip_flips=clip_flips,
+                oracle_losses=ol, oracle_grads=ref, hip_grads=hip)
+
+
+def report_attribution(tag, r) -> None:
+    rows = r['rows']
+    print(f"[{tag}] {r['flips']} of {r['npix']} selections differ (largest candidate gap {r['gap']:.2e}), {r['cell_flips']} "
+          f"bilinear cells and {r['clip_flips']} clip flags of {2 * r['npix']} samples; worst rel-L2 of the 36 gradient tensors "
+          f"vs the oracle {max(x[1] for x in rows):.2e}, on the same selection {max(x[2] for x in rows):.2e}, on the same "
+          f"selection + cells + clips {max(x[4] for x in rows):.2e}")
+    for x in sorted(rows, key=lambda x: -x[1])[:4]:
+        print(f'    {x[0]:44s} free {x[1]:.2e}  same selection {x[2]:.2e}  + cells/clips {x[4]:.2e}')

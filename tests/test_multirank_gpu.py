@@ -60,6 +60,10 @@ def _dp_worker(rank, world, port, H, W, counts, steps, frames, lcd, async_tail, 
         if enc is not None:                                                           # slam.py:180,223: rgb(+1, 0) of the online frame
             feats.append(enc(full['rgb', 1, 0][:1].cuda()).cpu())
         out, losses = p.adapt(None, batch, steps=steps)
+        if f == 0:
+            p.engine.wait_training()
+            first = {'g': p.engine.g.clone().cpu(), 'loss': {k: v.detach().cpu().clone() for k, v in losses.items()},
+                     'depth': out['depth', 0].cpu()}
         rec = (out, losses)
     out, losses = rec
     everything = p.gather_outputs(out)
@@ -74,7 +78,7 @@ def _dp_worker(rank, world, port, H, W, counts, steps, frames, lcd, async_tail, 
     cpu = lambda t: t.detach().cpu()      # noqa: E731
     torch.save({'in_sync': in_sync, 'diverged_seen': diverged_seen, 'full_depth': cpu(everything['depth', 0]),
                 'full_T': cpu(everything['cam_T_cam', 0, -1]), 'g': cpu(p.engine.g), 'w': cpu(p.engine.w), 'm': cpu(p.engine.m),
-                'loss': {k: cpu(v).clone() for k, v in losses.items()}, 'T': cpu(out['cam_T_cam', 0, 1]), 'feats': feats},
+                'loss': {k: cpu(v).clone() for k, v in losses.items()}, 'T': cpu(out['cam_T_cam', 0, 1]), 'feats': feats, 'first': first},
                Path(out_dir) / f'rank{rank}_{int(async_tail)}.pt')
     dist.barrier()
     dist.destroy_process_group()
@@ -100,21 +104,29 @@ def test_two_ranks_on_one_gpu_equal_single_rank(tmp_path, H, W, counts, lcd):
     for f in range(frames):
         p.set_tie_break_noise({s: v.cuda() for s, v in synth.make_noise(B, H, W, seed=8 + f).items()})
         out, losses = p.adapt(None, {k: v.clone() for k, v in synth.make_batch(B, H, W, seed=4 + f).items()}, steps=steps)
+        if f == 0:
+            g_first, loss_first, depth_first = p.engine.g.cpu(), {k: float(v) for k, v in losses.items()}, out['depth', 0].cpu()
     torch.cuda.synchronize()
-    g, w = p.engine.g.cpu(), p.engine.w.cpu()
+    w = p.engine.w.cpu()
     for t in (0, 1):
         r0, r1 = r[0, t], r[1, t]
         # identical replicas after the all-reduce + Adam, checksum check works on device tensors
         assert torch.equal(r0['g'], r1['g']) and torch.equal(r0['w'], r1['w']) and torch.equal(r0['m'], r1['m'])
         assert r0['in_sync'] and r1['in_sync'] and r0['diverged_seen'] and r1['diverged_seen']
         assert torch.equal(r0['full_depth'], r1['full_depth']) and r0['full_depth'].shape == out['depth', 0].shape
-        # second frame's step on weights one update old: piecewise-smooth loss, stream-K cuts differ per shard size
-        e_g = float((r0['g'] - g).abs().max() / g.abs().max())
-        assert e_g < 5e-2, e_g
-        assert float((r0['w'] - w).abs().max()) < 4.5e-4                       # at most a couple of lr-sized flips
-        assert torch.allclose(r0['full_depth'], out['depth', 0].cpu(), rtol=2e-2, atol=0)
-        for k, v in losses.items():
-            assert abs(float(r0['loss'][k]) - float(v)) <= 2e-3 * max(abs(float(v)), 1e-3), k
+        # first frame (same weights everywhere): the all-reduced gradient is the single-process gradient up to summation
+        # order, the stream-K cuts (they follow the shard size) and a handful of kink flips of the piecewise-smooth loss
+        # (tests/test_full_size.py holds the same shard-sum rule inside one process)
+        e_g = float((r0['first']['g'] - g_first).abs().max() / g_first.abs().max())
+        assert e_g < 2e-2, e_g
+        for k, v in loss_first.items():
+            assert abs(float(r0['first']['loss'][k]) - v) <= 1e-4 * max(abs(v), 1e-3), k
+        assert torch.allclose(r0['first']['depth'], depth_first[:counts[0]], rtol=1e-4, atol=0)
+        # second frame: Adam's first update is lr * sign(g), so near-zero gradient entries land on either side and the
+        # weights -- and with them the second step -- differ by lr-sized flips: bounded, not compared tightly
+        assert float((r0['w'] - w).abs().max()) < 4.5e-4
+        assert torch.allclose(r0['full_depth'], out['depth', 0].cpu(), rtol=5e-2, atol=0)
+        assert all(torch.isfinite(v).all() for v in r0['loss'].values())
     # the asynchronous tail is invisible: bitwise the serial order (same shards, same kernels, same all-reduce)
     for k in (0, 1):
         for name in ('g', 'w', 'm', 'full_depth', 'T'):

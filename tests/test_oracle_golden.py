@@ -153,3 +153,50 @@ def test_adapt_full_size_matches_reference():
     losses['loss'].backward()
     grads = {f'{m}/{k}': prm.grad for m in ('depth_decoder', 'pose_decoder') for k, prm in o.models[m].named_parameters()}
     _check_full_size(g, out, {k: v.detach() for k, v in losses.items()}, grads, 2e-5, 2e-6, 2e-5)
+
+
+def test_written_out_grid_sampler_equals_torch_grid_sample():
+    """oracle.functional.grid_sample_border (the sampler that can take another implementation's cell / clip decisions,
+    tests/test_backward_parity.py) against F.grid_sample(padding_mode='border', align_corners=True) itself: values,
+    gradient w.r.t. the grid (incl. the zeroed gradient of clipped coordinates) and w.r.t. the image; then inside the
+    oracle's adapt step: the losses and all 36 gradients are those of the F.grid_sample path."""
+    import torch.nn.functional as F
+    from oracle import functional as OF
+    g = torch.Generator().manual_seed(11)
+    B, C, H, W = 2, 3, 12, 20
+    src = torch.rand(B, C, H, W, generator=g, requires_grad=True)
+    grid = (torch.rand(B, H, W, 2, generator=g) * 2.6 - 1.3)            # a fifth of the samples outside the image
+    grid[0, 0, :4, 0] = torch.tensor([-1.0, 1.0, -1.0 + 2.0 * 3 / (W - 1), 1.0 - 2.0 / (W - 1)])   # exactly on pixels / borders
+    grid.requires_grad_(True)
+    up = torch.rand(B, C, H, W, generator=g)
+    ref = F.grid_sample(src, grid, padding_mode='border', align_corners=True)
+    gs_ref, gg_ref = torch.autograd.grad((ref * up).sum(), (src, grid))
+    rec = []
+    got = OF.grid_sample_border(src, grid, record=rec)
+    gs, gg = torch.autograd.grad((got * up).sum(), (src, grid))
+    assert torch.allclose(got, ref, atol=2e-7, rtol=1e-6)
+    assert torch.allclose(gg, gg_ref, atol=1e-5, rtol=1e-5) and torch.allclose(gs, gs_ref, atol=1e-6, rtol=1e-6)
+    assert float((gg_ref == 0).float().mean()) > 0.1                       # clipped samples are really in the test
+    # imposing its own recorded decisions changes nothing
+    again = OF.grid_sample_border(src, grid, cells=rec[0])
+    assert torch.equal(again, got)
+    # inside the step
+    Hh, Ww, Bb = 64, 128, 2
+    batch = synth.make_batch(Bb, Hh, Ww, seed=3)
+    noise = synth.make_noise(Bb, Hh, Ww, seed=13)
+    res, sel = [], None
+    for manual in (False, True):
+        o = make_oracle(Hh, Ww, Bb)
+        o.record_cells = manual
+        # the two samplers agree to the last bit or two, which is enough to flip the 4-way min at a near-tie pixel (1-2 of
+        # 65,536 here, each worth ~1e-2 of a gradient tensor -- DESIGN.md section 2): compare on the same selection
+        o.forced_sel = sel
+        o.set_adapt()
+        _, losses = o.process_batch(batch, noise, None)
+        o.optimizer.zero_grad()
+        losses['loss'].backward()
+        res.append((float(losses['loss'].detach()), [p.grad.clone() for m in ('depth_decoder', 'pose_decoder') for p in o.models[m].parameters()]))
+        sel = dict(o.last_sel)
+    assert abs(res[0][0] - res[1][0]) <= 1e-6 * abs(res[0][0])
+    for a, b in zip(res[0][1], res[1][1]):
+        assert float((a - b).norm() / a.norm().clamp_min(1e-30)) < 1e-4        # fp32 summation order (2.7e-5 measured)

@@ -99,25 +99,22 @@ def test_adapt_matches_reference_golden(backend, case, B, steps):
             ref = float(g[pre + 'loss/' + k])
             assert abs(float(v) - ref) <= tol * max(abs(ref), 1e-3), (it, k, float(v), ref)
         if it == 0:
-            eng = p.engine
-            import math
-            from clslam_hip.engine import TrainableLayout
-            for name, off, shape in eng.layout.entries:
-                n = math.prod(shape)
-                grad = TrainableLayout.to_reference(eng.g[off:off + n], shape).cpu()
+            # Gradients, as FULL tensors.  The golden file holds the reference's gradient norms and 96-element slices;
+            # the oracle reproduces them (here: 1e-5; test_oracle_golden.py: the whole fixture), so the oracle's
+            # autograd IS the reference's gradient on these inputs.  The loss is only piecewise smooth (4-way min, bilinear
+            # cells, border clips, |.|) and the kernel path's projected positions differ from torch's by ~1e-5 px: a
+            # handful of samples take a decision the other way, each worth up to ~1e-2 of a tensor.  Those decisions are
+            # read out of the kernel path and imposed on the oracle; all 36 tensors then agree to 5e-4.
+            from helpers import attributed_gradient_errors
+            dev = p.device
+            r = attributed_gradient_errors(p, batch, synth.make_noise(B, H, W, seed=11), dev)
+            for name, ref_grad in r['oracle_grads'].items():
                 gn = float(g[pre + 'gradnorm/' + name])
-                # End-to-end gradients are compared loosely: the loss is only piecewise smooth (bilinear
-                # cell boundaries, border clipping, 4-way min, |.|), and the warp coordinates differ from
-                # torch's BLAS-evaluated projection by ~1e-5 px, so roughly one pixel per step lands on the
-                # other side of a kink and moves a layer's gradient by up to ~1 %.  The kernels themselves
-                # are held to 2e-4 / 2e-5 in test_loss_stage.py / test_conv_bwd.py.
-                assert abs(float(grad.double().norm()) - gn) <= 3e-2 * gn + 2e-6, (name, float(grad.double().norm()), gn)  # +abs: 1-element
-                # bias gradients are residues of heavily cancelling sums
-                sl = g[pre + 'gradslice/' + name]
-                scale = max(float(np.abs(sl).max()), gn / math.sqrt(n))
-                # an isolated near-tie flip in the 4-way min (see tests/test_loss_stage.py) perturbs
-                # individual gradient entries at the 1e-2 level of the tensor's typical magnitude
-                assert float((grad.reshape(-1)[:96] - torch.from_numpy(sl)).abs().max()) <= 5e-2 * scale, name
+                assert abs(float(ref_grad.double().norm()) - gn) <= 1e-5 * gn + 1e-9, name
+                assert float((ref_grad.reshape(-1)[:96] - torch.from_numpy(g[pre + 'gradslice/' + name])).abs().max()) <= 1e-5 * max(gn, 1e-6)
+            assert r['flips'] <= 2e-4 * r['npix'] and r['cell_flips'] + r['clip_flips'] <= 1e-3 * r['npix']
+            for name, e_free, e_sel, norm, e_all in r['rows']:
+                assert e_all < 5e-4, (name, e_free, e_sel, e_all)
         # adapted weights vs the reference's, in units of the learning rate (golden holds the first
         # 96 entries of every trainable tensor): at most a few percent may differ by a flipped update
         import math as _m
