@@ -77,9 +77,10 @@ def disp_to_depth(disp: Tensor, min_depth: Optional[float], max_depth: Optional[
 def backproject(depth: Tensor, inv_K: Tensor) -> Tensor:
     """networks/layers.py:51-79.  depth (B,1,H,W) -> homogeneous points (B,4,H*W)."""
     B, _, H, W = depth.shape
-    ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float32),
-                            torch.arange(W, dtype=torch.float32), indexing='ij')
-    ones = torch.ones(B, 1, H * W)
+    # (depth.dtype: fp32 like the reference; the fp64 re-run of tests/helpers.py attributes fp32 rounding)
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=depth.dtype),
+                            torch.arange(W, dtype=depth.dtype), indexing='ij')
+    ones = torch.ones(B, 1, H * W, dtype=depth.dtype)
     pix = torch.stack([xs.reshape(-1), ys.reshape(-1)], 0).unsqueeze(0).repeat(B, 1, 1)
     pix = torch.cat([pix, ones], 1)
     cam = torch.matmul(inv_K[:, :3, :3], pix)
@@ -122,8 +123,12 @@ def grid_sample_border(src: Tensor, grid: Tensor, cells=None, record=None) -> Te
         x0, y0, mx, my = cells
     if record is not None:
         record.append((x0, y0, mx, my))
-    ixc = torch.where(mx, ix, ix.detach().clamp(0, W - 1))      # clipped coordinate; no gradient where clipped
-    iyc = torch.where(my, iy, iy.detach().clamp(0, H - 1))
+    if cells is None:
+        ixc = torch.where(mx, ix, ix.detach().clamp(0, W - 1))      # clipped coordinate; no gradient where clipped
+        iyc = torch.where(my, iy, iy.detach().clamp(0, H - 1))
+    else:   # an imposed clip puts the sample ON the border pixel the other implementation chose (its x0 is 0 or W-1 there)
+        ixc = torch.where(mx, ix, x0.to(ix.dtype))
+        iyc = torch.where(my, iy, y0.to(iy.dtype))
     wx1, wy1 = ixc - x0.to(ix.dtype), iyc - y0.to(iy.dtype)
     wx0, wy0 = (x0 + 1).to(ix.dtype) - ixc, (y0 + 1).to(iy.dtype) - iyc
     x1ok, y1ok = (x0 + 1 <= W - 1), (y0 + 1 <= H - 1)
@@ -217,10 +222,10 @@ def velocity_loss(trans_m1: Tensor, trans_p1: Tensor, dist0: Tensor, dist1: Tens
     pairs translation(0->+1) with relative_distance(1); L1 in the promoted dtype
     (relative_distance is float64), accumulated into an fp32 vector, /2."""
     B = trans_m1.shape[0]
-    out = torch.zeros(B, dtype=torch.float32)
+    out = torch.zeros(B, dtype=trans_m1.dtype)       # fp32 in the reference
     for pred_t, gt in ((trans_m1, dist0), (trans_p1, dist1)):
         gt_d = torch.abs(gt).reshape(B)
         pred_d = torch.linalg.norm(pred_t, dim=-1).reshape(B)
         # in-place fp32 += fp64 computes in fp64 and rounds back to fp32 (dpp.py:1142)
-        out = (out.double() + F.l1_loss(pred_d.double(), gt_d.double(), reduction='none')).float()
+        out = (out.double() + F.l1_loss(pred_d.double(), gt_d.double(), reduction='none')).to(trans_m1.dtype)
     return out / 2

@@ -30,6 +30,10 @@ class OraclePredictor:
         # test hooks for the view synthesis (functional.grid_sample_border): forced_cells[s][f] = (x0, y0, mx, my) imposes
         # the bilinear cell / clip decisions of another implementation; record_cells=True keeps this run's own in last_cells
         self.forced_cells, self.record_cells, self.last_cells = None, False, {}
+        # forced_forward = {('disp', s): tensor, ('cam_T_cam', 0, f): tensor}: evaluate loss and backward AT another
+        # implementation's forward point (value replaced, gradient path kept: x + (x_other - x).detach()) -- separates the
+        # rounding of the forward pass, which the ill-conditioned loss amplifies, from the arithmetic of the backward pass
+        self.forced_forward = None
         self.frame_ids = (0, -1, 1)
         # dpp.py:129-137 (dict insertion order defines the optimizer's parameter order)
         self.models = {
@@ -65,6 +69,10 @@ class OraclePredictor:
         outputs: Dict[Any, Tensor] = {}
         feats = self.models['depth_encoder'](inputs[('rgb_aug', 0, 0)])  # dpp.py:931-936
         outputs.update(self.models['depth_decoder'](feats))
+        if self.forced_forward is not None:
+            for s in self.scales:
+                d = outputs[('disp', s)]
+                outputs[('disp', s)] = d + (self.forced_forward['disp', s].to(d.dtype) - d).detach()
         T = {}
         for f in (-1, 1):  # dpp.py:938-974
             pair = ([inputs['rgb_aug', f, 0], inputs['rgb_aug', 0, 0]] if f < 0 else
@@ -75,6 +83,8 @@ class OraclePredictor:
             outputs[('axis_angle', 0, f)] = aa
             outputs[('translation', 0, f)] = tr
             T[f] = OF.transformation_from_parameters(aa, tr, invert=f < 0)
+            if self.forced_forward is not None:
+                T[f] = T[f] + (self.forced_forward['cam_T_cam', 0, f].to(T[f].dtype) - T[f]).detach()
             outputs[('cam_T_cam', 0, f)] = T[f]
         src = {f: inputs[('rgb', f, 0)] for f in (-1, 1)}
         for s in self.scales:  # dpp.py:976-1017

@@ -57,7 +57,9 @@ def attributed_gradient_errors(p, batch, noise, dev):
     tensors, relative L2) with the oracle's autograd three times: free; with the oracle forced to the kernel path's 4-way-min
     selection; and with the kernel path's bilinear cells and border-clip flags imposed on the oracle's written-out sampler
     as well (clslam_warp_cells_pyramid -> oracle.functional.grid_sample_border).  Returns a dict with the flip counts,
-    the rows (name, e_free, e_same_selection, norm, e_same_decisions) and the free oracle's losses / gradients."""
+    the rows (name, e_free, e_same_selection, norm, e_same_decisions, kernels vs float64 oracle on those decisions, torch fp32
+    vs the same, kernels vs float64 at the kernel path's forward point, torch fp32 vs the same) and the free oracle's
+    losses / gradients."""
     import math
     from clslam_hip import ops
     from clslam_hip.engine import TrainableLayout
@@ -90,7 +92,7 @@ def attributed_gradient_errors(p, batch, noise, dev):
     cells = torch.empty(4, 2, B, H, W, dtype=torch.int32, device=dev)
     ops.warp_cells_pyramid(ws.disp, ws.ctx.Kinv, ws.P, cells, p.min_depth, p.max_depth)
     cells = cells.cpu()
-    forced_cells, cell_flips, clip_flips = {}, 0, 0
+    forced_cells, cell_flips, clip_flips, far_cells = {}, 0, 0, 0
     for s in range(4):
         forced_cells[s] = {}
         for fi, f in enumerate((-1, 1)):
@@ -99,22 +101,53 @@ def attributed_gradient_errors(p, batch, noise, dev):
             forced_cells[s][f] = mine
             theirs = o2.last_cells[s][f]
             cell_flips += int(((mine[0] != theirs[0]) | (mine[1] != theirs[1])).sum())
+            # more than one cell apart: not a sample on a cell boundary but an ill-conditioned projection (denominator near 0)
+            far_cells += int((((mine[0] - theirs[0]).abs() > 1) | ((mine[1] - theirs[1]).abs() > 1)).sum())
             clip_flips += int(((mine[2] != theirs[2]) | (mine[3] != theirs[3])).sum())
     o3 = make_oracle(H, W, B)
     o3.forced_sel = {s: sel_hip[s] for s in range(4)}
     o3.forced_cells = forced_cells
     _, _, forced3 = oracle_grads(o3, batch, noise)
+    # (d) the same decisions once more in float64: what is left between an fp32 implementation and THIS is rounding.  The
+    # gradients are sums of millions of terms of both signs (and 1/depth, 1/den factors of an untrained network), so fp32
+    # rounding alone moves them by 1e-4 ... 1e-2 of their norm -- in torch's fp32 as much as in the kernels'.
+    b64 = {k: (v.double() if v.is_floating_point() else v) for k, v in batch.items()}
+    n64 = {s: v.double() for s, v in noise.items()}
+
+    def exact_run(forward_point, double=True):
+        o4 = make_oracle(H, W, B)
+        if double:
+            for m in o4.models.values():
+                m.double()
+        o4.forced_sel, o4.forced_cells, o4.forced_forward = o3.forced_sel, forced_cells, forward_point
+        return oracle_grads(o4, b64 if double else batch, n64 if double else noise)[2]
+    exact = exact_run(None)
+    # (e) ... and AT THE KERNEL PATH'S FORWARD POINT: its disparities and pose matrices (1e-6 / 3e-8 from the oracle's) replace
+    # the oracle's values, the gradient path stays.  The loss is so ill-conditioned that this rounding of the FORWARD pass,
+    # coherent over all pixels of a frame, is most of (d); what remains here is the arithmetic of the BACKWARD pass alone.
+    outs = p.engine._outputs(ws, B)
+    point = {**{('disp', s): outs['disp', s].detach().cpu() for s in range(4)},
+             **{('cam_T_cam', 0, f): outs['cam_T_cam', 0, f].detach().cpu() for f in (-1, 1)}}
+    exact_pt = exact_run(point)
+    fp32_pt = exact_run(point, double=False)
     rows = [(name, rel_l2(hip[name], ref[name]), rel_l2(hip[name], forced[name]), float(ref[name].norm()),
-             rel_l2(hip[name], forced3[name])) for name in hip]
-    return dict(flips=flips, npix=4 * B * H * W, gap=worst_gap, rows=rows, cell_flips=cell_flips, clip_flips=clip_flips,
+             rel_l2(hip[name], forced3[name]), rel_l2(hip[name], exact[name]), rel_l2(forced3[name], exact[name]),
+             rel_l2(hip[name], exact_pt[name]), rel_l2(fp32_pt[name], exact_pt[name])) for name in hip]
+    return dict(flips=flips, npix=4 * B * H * W, gap=worst_gap, rows=rows, cell_flips=cell_flips, clip_flips=clip_flips, far_cells=far_cells,
                 oracle_losses=ol, oracle_grads=ref, hip_grads=hip)
 
 
 def report_attribution(tag, r) -> None:
     rows = r['rows']
     print(f"[{tag}] {r['flips']} of {r['npix']} selections differ (largest candidate gap {r['gap']:.2e}), {r['cell_flips']} "
-          f"bilinear cells and {r['clip_flips']} clip flags of {2 * r['npix']} samples; worst rel-L2 of the 36 gradient tensors "
+          f"bilinear cells ({r['far_cells']} of them by more than one cell) and {r['clip_flips']} clip flags of {2 * r['npix']} samples; worst rel-L2 of the 36 gradient tensors "
           f"vs the oracle {max(x[1] for x in rows):.2e}, on the same selection {max(x[2] for x in rows):.2e}, on the same "
-          f"selection + cells + clips {max(x[4] for x in rows):.2e}")
-    for x in sorted(rows, key=lambda x: -x[1])[:4]:
-        print(f'    {x[0]:44s} free {x[1]:.2e}  same selection {x[2]:.2e}  + cells/clips {x[4]:.2e}')
+          f"selection + cells + clips {max(x[4] for x in rows):.2e}; against the float64 oracle on those decisions: kernels "
+          f"{max(x[5] for x in rows):.2e}, torch fp32 {max(x[6] for x in rows):.2e}; the same at the kernel path's forward point "
+          f"(backward arithmetic only): kernels {max(x[7] for x in rows):.2e}, torch fp32 {max(x[8] for x in rows):.2e}")
+    shown = sorted(rows, key=lambda x: -x[1])[:4]
+    shown += [x for x in sorted(rows, key=lambda x: -x[4])[:3] if x not in shown]
+    shown += [x for x in sorted(rows, key=lambda x: -x[7])[:2] if x not in shown]
+    for x in shown:
+        print(f'    {x[0]:44s} free {x[1]:.2e}  same selection {x[2]:.2e}  + cells/clips {x[4]:.2e}   vs float64: kernels {x[5]:.2e}  '
+              f'torch fp32 {x[6]:.2e}   at the same forward point: kernels {x[7]:.2e}  torch fp32 {x[8]:.2e}')

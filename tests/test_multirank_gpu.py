@@ -125,7 +125,8 @@ def test_two_ranks_on_one_gpu_equal_single_rank(tmp_path, H, W, counts, lcd):
         # second frame: Adam's first update is lr * sign(g), so near-zero gradient entries land on either side and the
         # weights -- and with them the second step -- differ by lr-sized flips: bounded, not compared tightly
         assert float((r0['w'] - w).abs().max()) < 4.5e-4
-        assert torch.allclose(r0['full_depth'], out['depth', 0].cpu(), rtol=5e-2, atol=0)
+        rel = ((r0['full_depth'] - out['depth', 0].cpu()).abs() / out['depth', 0].cpu().abs()).mean()
+        assert float(rel) < 1e-2, float(rel)
         assert all(torch.isfinite(v).all() for v in r0['loss'].values())
     # the asynchronous tail is invisible: bitwise the serial order (same shards, same kernels, same all-reduce)
     for k in (0, 1):
