@@ -6,7 +6,10 @@
 
 One "step" = one `DepthPosePrediction.adapt(online, training, steps=1)`: forward of both networks,
 view synthesis + loss, hand-written backward, fused Adam -- on a synthetic minibatch of 1 online
-triplet + R replayed triplets that is already resident in HBM (BASELINE.json metric).
+triplet + R replayed triplets that is already resident in HBM when the timed region starts (bench contract), followed by
+what slam/slam.py:181-188 does with the result every frame: the online sample's pose and every loss scalar read back to
+the host (`--no-readback` leaves that out).  The PCIe-inclusive frame of SURVEY.md 8(d) (pinned host minibatch -> H2D
+inside adapt()) is measured by the same run and reported under `also.end_to_end`; by the contract it is never `value`.
 N = 1 runs BASELINE config 3 (R = 4, B = 5, the configuration the 30 frames/s target is quoted on);
 `--replay R` selects another replay count (R = 0 is BASELINE config 2).
 N > 1 shards a minibatch data-parallel with ONE sum-all-reduce of the flat gradient arena per step over
@@ -38,7 +41,7 @@ import torch  # noqa: E402
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4_f32
 
 
-def build_predictor(H, W, B_cfg):
+def build_predictor(H, W, B_cfg, host_outputs=True):
     from types import SimpleNamespace
     from clslam_hip import synth
     from depth_pose_prediction import Config, DepthPosePrediction
@@ -50,7 +53,9 @@ def build_predictor(H, W, B_cfg):
                  velocity_loss_scaling=0.05, mask_dynamic=False, log_path=Path('/tmp/clslam_bench'), save_frequency=-1,
                  save_val_depth=False, save_val_depth_batches=0, multiple_gpus=False, gpu_ids=None,
                  load_weights_folder=None, use_wandb=False)
-    p = DepthPosePrediction(ds, cfg)
+    # host_outputs: the opt-in fast path of the product (pose + losses handed out as host tensors staged behind the forward,
+    # DepthPosePrediction(host_pose_output=True) / CLSLAM_HOST_POSE=1); False = the reference's behaviour (device tensors)
+    p = DepthPosePrediction(ds, cfg, host_pose_output=host_outputs)
     for name, m in p.models.items():  # random-init weights of the reference architecture (closed form)
         m.load_state_dict(synth.fill_state_dict(torch.nn.Module.state_dict(m), 0, name))
     p.is_trained = True
@@ -115,8 +120,11 @@ def main():
     ap.add_argument('--random-images', action='store_true', help='uniform-random image content instead of the smooth synthetic '
                     'frames (SURVEY.md 8d: the photometric min / mask then flips per pixel -- worst case for the loss stage)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--readback', action='store_true', help='also read the pose and the loss scalars back to the host inside '
-                    'the timed region of `value` (slam.py:182-192); always part of also.end_to_end')
+    ap.add_argument('--no-readback', action='store_true', help='do not read the pose and the loss scalars back to the host inside '
+                    'the timed region of `value` (slam.py:181-188 does, every frame)')
+    ap.add_argument('--device-outputs', action='store_true', help='reference-default boundary: adapt() returns pose and losses as '
+                    'device tensors (the readback then waits for the backward + optimizer step); default here is the '
+                    'product\'s opt-in host-output fast path (host_pose_output=True)')
     ap.add_argument('--no-also', action='store_true', help='skip the extra adapt(steps=5) timing (profiling runs)')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo lets two '
                     'ranks share one GPU for a functional check of the sharded path)')
@@ -150,9 +158,10 @@ def main():
     offset = sum(counts[:rank])
     Bl = counts[rank]
 
-    from clslam_hip import ops, synth
+    from clslam_hip import _lib, ops, synth
+    build_id = _lib.build_id()
     torch.manual_seed(1 + rank)          # the tie-break noise is drawn on the device: same trajectory every run
-    p = build_predictor(H, W, B if N == 1 else Bl)
+    p = build_predictor(H, W, B if N == 1 else Bl, host_outputs=not args.device_outputs)
     if N > 1:
         p.enable_data_parallel(B, offset)
     full = synth.make_batch(B, H, W, seed=0)
@@ -178,7 +187,7 @@ def main():
 
     def step():
         out = p.adapt(None, batch, steps=S)
-        if args.readback:
+        if not args.no_readback:
             consume(*out)
         return out
 
@@ -221,12 +230,28 @@ def main():
             sync()
             groups.append((time.perf_counter() - t0) / 10 * 1e3)
         ms_e2e = sorted(groups)[1]
-        up = [k for k in p.UPLOAD_FIRST + p.UPLOAD_REST if k in host]
+        # the same frame with the reference's default boundary (pose + losses as device tensors: the first .cpu() waits for
+        # the backward + optimizer step, then one small D2H per loss key)
+        prev = p.host_pose_output
+        p.host_pose_output = False
+        frame()
+        ref_groups = []
+        for _ in range(2):
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                frame()
+            sync()
+            ref_groups.append((time.perf_counter() - t0) / 10 * 1e3)
+        p.host_pose_output = prev
+        up = [k for k in host if isinstance(host[k], torch.Tensor)] if p.upload_all_inputs else [k for k in p.UPLOAD_FIRST + p.UPLOAD_REST if k in host]
         e2e = {'ms_per_frame': round(ms_e2e, 3), 'frames_per_s': round(1e3 / ms_e2e, 2),
                'h2d_mbytes_per_frame': round(sum(host[k].numel() * host[k].element_size() for k in up) / 1e6, 2),
                'h2d_tensors': len(up), 'of_tensors_in_sample_dict': len(host),
-               'includes': 'H2D of the 13 tensors the path reads from pinned host memory (copy stream, network inputs first), '
-                           'adapt(), D2H of cam_T_cam[0] and the loss scalars (slam.py:182-192)'}
+               'ms_per_frame_with_device_outputs': round(min(ref_groups), 3),
+               'includes': 'H2D of the whole sample dict from pinned host memory (dpp.py:916-917; copy stream, network inputs '
+                           'first, entries the path never reads last), adapt(), cam_T_cam[0] and the loss scalars on the host '
+                           '(slam.py:181-188)'}
 
     also = None
     if N == 1 and S == 1 and not args.no_also:
@@ -291,13 +316,19 @@ def main():
         (kind, cfg), (fl, tt, cnt, nb) = max(agg.items(), key=lambda kv: kv[1][1])
         all_fl = sum(a[0] for a in agg.values())
         all_t = sum(a[1] for a in agg.values())
-        traffic = None
-        try:  # L2-miss bytes per launch of this kernel from the committed rocprofv3 PMC passes (profiles/)
-            traffic = json.load(open(ROOT / 'profiles' / 'pmc_traffic.json'))[names[cfg]]['traffic_bytes_per_launch']
-        except Exception:
-            pass
+        # L2-miss bytes per launch of this kernel from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json, written by
+        # tools/measure_round.sh) -- only if those passes ran on THIS build of the kernels (same source id), else null
+        traffic, traffic_note = None, None
+        try:
+            pmc = json.load(open(ROOT / 'profiles' / 'pmc_traffic.json'))
+            if pmc.get('_build_id') == build_id:
+                traffic = pmc[names[cfg]]['traffic_bytes_per_launch']
+            else:
+                traffic_note = f"profiles/pmc_traffic.json was taken on build {pmc.get('_build_id')}, this is {build_id}"
+        except Exception as e:
+            traffic_note = f'no counter entry: {type(e).__name__}'
         roof = {'bound': 'mfma', 'achieved': round(fl / tt / 1e12, 2), 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': round(fl / tt / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': traffic,
+                'frac': round(fl / tt / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': traffic, 'traffic_note': traffic_note,
                 'algorithmic_bytes_per_launch_avg': round(nb / cnt),
                 'kernel': names[cfg], 'launches_per_step': cnt,
                 'avg_launch_us': round(tt / cnt * 1e6, 2), 'flops_per_launch_avg': fl / cnt,
@@ -317,7 +348,13 @@ def main():
                                    f'a frame = {FRAME_TRIPLETS} triplets (value = steps/s * B/{FRAME_TRIPLETS})',
                        'global_batch': B, 'replay_k': K, 'height': H, 'width': W, 'adapt_steps_per_frame': S,
                        'parallelism': f'dp{N}' if N > 1 else 'single', 'shards': counts,
+                       'timed_region': 'minibatch resident in HBM -> adapt() -> ' + ('nothing read back' if args.no_readback else
+                                       'cam_T_cam[0] and every loss scalar on the host (slam.py:181-188)'),
+                       'boundary': 'reference default: outputs and losses are device tensors' if args.device_outputs else
+                                   'opt-in host-output fast path (host_pose_output=True): pose + losses handed out as host tensors '
+                                   'staged behind the forward',
                        'loss': float(losses['loss'])},
+            'build_id': build_id,
             'roofline': roof, 'cpu_baseline': cpu,
         }
         if also is not None:

@@ -186,3 +186,17 @@ def install_library_for_tests(path) -> Library:
 
 def exported_symbols():
     return ['clslam_last_error'] + list(_SIGNATURES)
+
+
+def build_id() -> str:
+    """Identity of the kernel sources the loaded library was built from (written by csrc/build.py at link time), checked
+    against the sources present: 'stale:<lib>/<src>' when they differ (a library older than its sources)."""
+    import importlib.util
+    csrc = Path(__file__).resolve().parents[1] / 'csrc'
+    spec = importlib.util.spec_from_file_location('_clslam_build', csrc / 'build.py')
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    src = mod.source_id()
+    f = Path(__file__).resolve().parents[1] / 'lib' / 'libclslam_hip.build_id'
+    built = f.read_text().strip() if f.exists() else 'unknown'
+    return built if built == src else f'stale:{built}/{src}'

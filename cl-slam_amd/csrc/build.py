@@ -22,6 +22,19 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-DCLSLAM_DEVICE
          '-I', str(CSRC / 'include'), '-Wno-unused-result']
 
 
+def source_id() -> str:
+    """Identity of the kernel sources (every .hip / .h under csrc/ + the public header, i.e. including the conv pick-config
+    table): 16 hex digits.  build() stores it next to the library; bench.py prints it and only pairs its timings with
+    rocprofv3 counter files (profiles/pmc_traffic.json) that carry the same id."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(CSRC.glob('*.hip')) + sorted(CSRC.glob('*.h')) + sorted((CSRC / 'include').rglob('*.h')) + [ROOT / 'include' / 'clslam_hip.h']
+    for f in files:
+        h.update(f.name.encode())
+        h.update(f.read_bytes())
+    return h.hexdigest()[:16]
+
+
 def _deps_mtime() -> float:
     hs = list(CSRC.glob('*.h')) + list((CSRC / 'include').rglob('*.h')) + [ROOT / 'include' / 'clslam_hip.h']
     return max(h.stat().st_mtime for h in hs)
@@ -59,6 +72,7 @@ def build(force: bool = False, verbose: bool = True) -> Path:
             raise RuntimeError(f'link failed:\n{r.stderr[-4000:]}')
         if verbose:
             print(f'[link] {lib}', flush=True)
+    (LIB_DIR / 'libclslam_hip.build_id').write_text(source_id() + '\n')
     return lib
 
 

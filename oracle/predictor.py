@@ -34,6 +34,8 @@ class OraclePredictor:
         # implementation's forward point (value replaced, gradient path kept: x + (x_other - x).detach()) -- separates the
         # rounding of the forward pass, which the ill-conditioned loss amplifies, from the arithmetic of the backward pass
         self.forced_forward = None
+        # forced_l1_sign[s][f] = sign(target - warped) of another implementation (functional.reprojection_loss)
+        self.forced_l1_sign = None
         self.frame_ids = (0, -1, 1)
         # dpp.py:129-137 (dict insertion order defines the optimizer's parameter order)
         self.models = {
@@ -109,7 +111,8 @@ class OraclePredictor:
         total = torch.zeros(1)
         target = inputs['rgb', 0, 0]
         for s in self.scales:
-            rp = torch.cat([OF.reprojection_loss(outputs['rgb', f, s], target)
+            rp = torch.cat([OF.reprojection_loss(outputs['rgb', f, s], target,
+                                                 None if self.forced_l1_sign is None else self.forced_l1_sign[s][f])
                             for f in (-1, 1)], 1)
             idl = torch.cat([OF.reprojection_loss(inputs['rgb', f, 0], target)
                              for f in (-1, 1)], 1)

@@ -41,6 +41,11 @@ def main():
                    'traffic_bytes_per_launch': int((2 * fk + wk) * 1024),
                    'note': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tools/measure_round.sh, serial launch '
                            'order); FETCH_SIZE doubled per MI355X_MICROARCH.md; includes Infinity-Cache hits (L2-miss traffic)'}
+    # identity of the kernel sources the counters were taken on (bench.py refuses to pair them with another build's timings)
+    from pathlib import Path
+    sys.path.insert(0, str(Path(__file__).resolve().parents[1] / 'cl-slam_amd'))
+    from clslam_hip import _lib
+    res['_build_id'] = _lib.build_id()
     json.dump(res, open(out, 'w'), indent=1)
     print(f'{len(res)} kernels -> {out}')
 
