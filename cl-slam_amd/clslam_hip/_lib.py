@@ -64,6 +64,7 @@ _SIGNATURES = {
     'clslam_conv_wgrad_patch': [C.POINTER(ConvDesc), fptr, fptr, i32, C.c_void_p],
     'clslam_reduce_partials': [fptr, fptr, C.c_size_t, i32, C.c_float, C.c_void_p],
     'clslam_reduce_multi': [fptr, i32, i32, C.c_void_p],
+    'clslam_reduce_multi_adam': [fptr, i32, i32, fptr, fptr, fptr, fptr, C.c_double, C.c_double, C.c_double, C.c_double, i32, fptr, C.c_void_p],
     'clslam_colsum_blocks': [i32],
     'clslam_colsum': [fptr, fptr, i32, i32, C.c_void_p],
     'clslam_stem_packed_size': [i32],

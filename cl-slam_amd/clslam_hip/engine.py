@@ -161,6 +161,11 @@ class Engine:
         # stream; the caller's stream does not wait for them, so the frozen encoders of step N+1 overlap the
         # xGMI all-reduce.  Whatever reads trainable state waits on the event (wait_training()).
         self.async_tail = False
+        self.data_parallel = False    # set by DepthPosePrediction.enable_data_parallel: an all-reduce sits between reduction and Adam
+        # single-GPU path: the gradient reduction and the optimizer step are ONE launch (clslam_reduce_multi_adam);
+        # backward(defer_reduce=True) leaves the reduction to adam()
+        self.fuse_adam = os.environ.get('CLSLAM_FUSE_ADAM', '1') != '0'
+        self._pending_reduce = None
         self.tail_stream = pool.get('tail')
         self._tail_event = None       # optimizer step in flight on tail_stream
         self._tail_open = False       # backward() left its reduction on tail_stream; adam() closes it
@@ -401,9 +406,13 @@ class Engine:
             self._conv_ws[handle] = torch.zeros(self.CONV_WS_BYTES, dtype=torch.uint8, device=self.device)
             ops.set_conv_workspace(handle, self._conv_ws[handle])
 
-    def _encoder(self, e, bufs, n: int, stem_inputs, waits=None, stream=None) -> List[torch.Tensor]:
+    def _encoder(self, e, bufs, n: int, stem_inputs, waits=None, stream=None, aux=None) -> List[torch.Tensor]:
         """stem_inputs: list of (img_a, img_b|None, batch offset, count); returns the 5 NHWC features.
-        waits: one event per stem launch (its input image still crossing PCIe) for the current stream to wait on."""
+        waits: one event per stem launch (its input image still crossing PCIe) for the current stream to wait on.
+        aux: a second stream for the three 1x1 stride-2 `downsample` convolutions of the stage entries.  They read the same
+        input as the stage's first 3x3 convolution and nothing depends on them until its second one, but at 0.16-0.3 GF
+        they are pure launch latency (~11 us each for ~1 us of MFMA work): on `aux` they run underneath conv1 instead of
+        between conv1 and conv2 of the chain.  `stream`: the stream this encoder's launches go to (needed with aux)."""
         for i, (img_a, img_b, off, cnt) in enumerate(stem_inputs):
             if waits is not None:
                 (stream or torch.cuda.current_stream(self.device)).wait_event(waits[i])
@@ -415,11 +424,22 @@ class Engine:
             for bi in range(2):
                 blk = e.blocks[li * 2 + bi]
                 t, y = bufs.t[li], bufs.y[li][bi]
-                ops.conv2d(x, blk.w1, t, scale=blk.s1, shift=blk.b1, ksize=3, stride=blk.stride, act=ACT_RELU)
-                res = x
+                res, joined = x, None
                 if blk.wd is not None:
                     res = bufs.ds[li]
+                    if aux is not None and stream is not None:
+                        evs = bufs.__dict__.setdefault('ds_events', {})
+                        fork, joined = evs.get(li) or evs.setdefault(li, (torch.cuda.Event(), torch.cuda.Event()))
+                        fork.record(stream)                 # x is complete on the chain's stream
+                        aux.wait_event(fork)
+                        with self._on(aux):
+                            ops.conv2d(x, blk.wd, res, scale=blk.sd, shift=blk.bd, ksize=1, stride=blk.stride, pad=0, act=ACT_NONE)
+                        joined.record(aux)
+                ops.conv2d(x, blk.w1, t, scale=blk.s1, shift=blk.b1, ksize=3, stride=blk.stride, act=ACT_RELU)
+                if blk.wd is not None and joined is None:
                     ops.conv2d(x, blk.wd, res, scale=blk.sd, shift=blk.bd, ksize=1, stride=blk.stride, pad=0, act=ACT_NONE)
+                if joined is not None:
+                    stream.wait_event(joined)
                 ops.conv2d(t, blk.w2, y, scale=blk.s2, shift=blk.b2, residual=res, ksize=3, act=ACT_RELU)
                 x = y
             feats.append(x)
@@ -559,6 +579,9 @@ class Engine:
                 have_noise = identity_and_noise()
             id_ready = torch.cuda.Event()
             id_ready.record(wg)
+        # the 1x1 downsample convolutions of both encoders go to the wgrad stream (idle during the forward once the identity
+        # maps are out); a captured graph keeps the serial order
+        ds_aux = wg if (os.environ.get('CLSLAM_DS_AUX', '1') != '0' and not self._capturing) else None
         if side is not None:
             main = self._main
             side.wait_stream(main)
@@ -569,13 +592,14 @@ class Engine:
                     pf4 = ws.pf4 if reuse else self._encoder(self.enc['pose_encoder'], ws.penc, 2 * B,
                                                              [(aug[-1], aug[0], 0, B), (aug[0], aug[1], B, B)],
                                                              waits=None if inputs_ready is None else inputs_ready[1:3],
-                                                             stream=side)[4]
+                                                             stream=side, aux=ds_aux)[4]
                     self.wait_training(side)      # the (frozen) encoder above does not need the optimizer step in flight
                     self._pose_decoder(ws, pf4)
                     return pf4
 
             def depth_encoder():
-                return ws.dfeats if reuse else self._encoder(self.enc['depth_encoder'], ws.denc, B, [(aug[0], None, 0, B)])
+                return ws.dfeats if reuse else self._encoder(self.enc['depth_encoder'], ws.denc, B, [(aug[0], None, 0, B)],
+                                                             stream=main, aux=ds_aux)
             # the host enqueues ~50 launches per branch (~0.7 ms): the depth branch is the longer
             # dependency chain (encoder + decoder), so its kernels go out first
             if reuse:                   # no encoders to hide the host's launches behind: the long chain goes out first
@@ -742,8 +766,10 @@ class Engine:
         if plan.colsum is not None:
             ops.colsum(dz, plan.colsum, out_shape[0] * out_shape[1] * out_shape[2], cout)
 
-    def backward(self, B: int) -> None:
-        """dL/d(trainable arena) for the last training forward; fills self.g (dpp.py:312)."""
+    def backward(self, B: int, defer_reduce: bool = False) -> None:
+        """dL/d(trainable arena) for the last training forward; fills self.g (dpp.py:312).
+        defer_reduce: the caller promises that adam() follows directly (adapt(), single GPU): the batched reduction of the
+        gradient partials is left to adam(), which fuses it with the update; self.g is complete after THAT launch."""
         ws = self._ws[B]
         t = ws.train
         c = ws.ctx
@@ -782,8 +808,16 @@ class Engine:
             self._backward_pose_decoder(ws, t, B, t)
         # one batched, deterministic reduction of every weight / bias gradient partial into the arena
         if t.table is None:
+            # (pose_2's gradients are written straight into the arena by pose_head_bwd: identity items, so that every
+            # trainable element is the output of exactly one item -- the fused reduction + Adam updates per item)
+            for key, n in (('pose_decoder/pose_2.weight', 12 * 256), ('pose_decoder/pose_2.bias', 12)):
+                sl = self._slot(self.g, key, n)
+                t.items.append((sl, sl, n, 1))
             t.table = ops.make_reduce_table(t.items, self.device)
-        if self._use_tail():
+        self._pending_reduce = None
+        if defer_reduce and self.fuse_adam and not self.data_parallel and not self._capturing and not self._use_tail():
+            self._pending_reduce = (t.table, len(t.items))
+        elif self._use_tail():
             # the partial buffers are complete on the current stream; the reduction, the all-reduce (caller, under
             # training_stream()) and Adam follow on the tail stream and nobody waits for them here
             self.tail_stream.wait_stream(self._main)
@@ -1034,7 +1068,13 @@ class Engine:
             self._tail_open = False
         else:
             self.wait_training()
-            ops.adam_step(self.w, self.g, self.m, self.v, lr, self.adam_step_count, betas[0], betas[1], eps, guard=guard)
+            if self._pending_reduce is not None:
+                table, nitems = self._pending_reduce
+                self._pending_reduce = None
+                ops.reduce_multi_adam(table, nitems, self.g, self.w, self.m, self.v, lr, self.adam_step_count, betas[0], betas[1],
+                                      eps, guard=guard)
+            else:
+                ops.adam_step(self.w, self.g, self.m, self.v, lr, self.adam_step_count, betas[0], betas[1], eps, guard=guard)
             self._tail_event = None
         self._modules_stale = True
 

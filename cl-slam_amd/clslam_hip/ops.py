@@ -246,6 +246,13 @@ def reduce_multi(table, nitems, stream_ref, blocks_per_item=384):
     _lib.get_lib().call('clslam_reduce_multi', table.data_ptr(), nitems, blocks_per_item, _stream(stream_ref))
 
 
+def reduce_multi_adam(table, nitems, grad, param, exp_avg, exp_avg_sq, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, guard=None,
+                      blocks_per_item=384):
+    """reduce_multi + the Adam update of every reduced element in the same launch (single-GPU path)"""
+    _lib.get_lib().call('clslam_reduce_multi_adam', table.data_ptr(), nitems, blocks_per_item, _p(grad), _p(param), _p(exp_avg),
+                        _p(exp_avg_sq), lr, beta1, beta2, eps, step, _p(guard), _stream(grad))
+
+
 def copy_multi(pairs, stream_ref=None):
     """pairs: [(src, dst), ...] device tensors of equal dtype / byte size, both contiguous -> one launch for all
     copies (instead of one torch copy kernel each)."""

@@ -372,8 +372,40 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
 // bias gradients of a step); blockIdx.y = item, blockIdx.x strides over the item's outputs.
 struct ReduceItem { const float* partial; float* out; unsigned long long n; int splits; float scale; };
 
-__global__ __launch_bounds__(256) void reduce_multi_kernel(const ReduceItem* __restrict__ items) {
+// ADAM: the optimizer step (adam.hip's operation order, torch.optim.Adam's) is applied to every reduced element on the spot --
+// single-GPU path only, where nothing sits between the gradient reduction and the update: one launch and one pass over
+// the gradient less per step.  The gradient arena is still written (callers and tests read it).
+struct AdamArgs {
+    const float* g_base;     // gradient arena; an item's `out` lies inside it, the same offset addresses p / m / v
+    float* p; float* m; float* v;
+    float step_size, w1, beta2, w2, bc2_sqrt, eps;
+    const float* guard;      // the step's loss: NaN -> gradients are reduced, nothing is updated
+};
+
+__device__ __forceinline__ void adam_apply(const AdamArgs& a, size_t idx, float gr) {
+    const float mk = a.m[idx] + (gr - a.m[idx]) * a.w1;
+    const float vk = a.v[idx] * a.beta2 + a.w2 * gr * gr;
+    a.m[idx] = mk; a.v[idx] = vk;
+    a.p[idx] = a.p[idx] - a.step_size * (mk / (sqrtf(vk) / a.bc2_sqrt + a.eps));
+}
+
+__device__ __forceinline__ void adam_apply4(const AdamArgs& a, size_t idx, const float4& g4) {   // idx: multiple of 4
+    float4 pp = *reinterpret_cast<float4*>(a.p + idx), mm = *reinterpret_cast<float4*>(a.m + idx), vv = *reinterpret_cast<float4*>(a.v + idx);
+    float* P = &pp.x; float* M = &mm.x; float* V = &vv.x;
+    const float G[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        M[k] = M[k] + (G[k] - M[k]) * a.w1;
+        V[k] = V[k] * a.beta2 + a.w2 * G[k] * G[k];
+        P[k] = P[k] - a.step_size * (M[k] / (sqrtf(V[k]) / a.bc2_sqrt + a.eps));
+    }
+    *reinterpret_cast<float4*>(a.p + idx) = pp; *reinterpret_cast<float4*>(a.m + idx) = mm; *reinterpret_cast<float4*>(a.v + idx) = vv;
+}
+
+template <bool ADAM>
+__global__ __launch_bounds__(256) void reduce_multi_kernel(const ReduceItem* __restrict__ items, AdamArgs ad) {
     __shared__ float4 red[256];
+    const bool update = ADAM && !(ad.guard && !(ad.guard[0] == ad.guard[0]));
     const ReduceItem it = items[blockIdx.y];
     // Lanes along the split axis (KL) by split count: the big-weight layers (most of the bytes) have <= 24
     // splits -> one thread per float4 output sums all of them from independent loads in flight, no LDS, no
@@ -403,6 +435,7 @@ __global__ __launch_bounds__(256) void reduce_multi_kernel(const ReduceItem* __r
                 }
                 s.x *= it.scale; s.y *= it.scale; s.z *= it.scale; s.w *= it.scale;
                 reinterpret_cast<float4*>(it.out)[i] = s;
+                if (ADAM && update) adam_apply4(ad, (size_t)(it.out - ad.g_base) + i * 4, s);
             }
             return;
         }
@@ -421,6 +454,7 @@ __global__ __launch_bounds__(256) void reduce_multi_kernel(const ReduceItem* __r
                 for (int q = 1; q < KL; ++q) { const float4 v = red[q * IL + il]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
                 t.x *= it.scale; t.y *= it.scale; t.z *= it.scale; t.w *= it.scale;
                 reinterpret_cast<float4*>(it.out)[i] = t;
+                if (ADAM && update) adam_apply4(ad, (size_t)(it.out - ad.g_base) + i * 4, t);
             }
             __syncthreads();
         }
@@ -437,6 +471,7 @@ __global__ __launch_bounds__(256) void reduce_multi_kernel(const ReduceItem* __r
             float t = red[il].x;
             for (int q = 1; q < KL; ++q) t += red[q * IL + il].x;
             it.out[i] = t * it.scale;
+            if (ADAM && update) adam_apply(ad, (size_t)(it.out - ad.g_base) + i, t * it.scale);
         }
         __syncthreads();
     }
@@ -588,9 +623,30 @@ extern "C" int clslam_reduce_multi(const void* items_dev, int nitems, int blocks
     CLSLAM_REQUIRE(items_dev && nitems >= 0 && blocks_per_item >= 1, "reduce_multi: bad args");
     static_assert(sizeof(ReduceItem) == 32, "ReduceItem layout");
     if (!nitems) return CLSLAM_OK;
-    hipLaunchKernelGGL(reduce_multi_kernel, dim3(blocks_per_item, nitems), dim3(256), 0, (hipStream_t)stream,
-                       (const ReduceItem*)items_dev);
+    hipLaunchKernelGGL(reduce_multi_kernel<false>, dim3(blocks_per_item, nitems), dim3(256), 0, (hipStream_t)stream,
+                       (const ReduceItem*)items_dev, AdamArgs{});
     return check_launch("reduce_multi");
+}
+
+// reduce_multi + the optimizer step on every reduced element (clslam_adam_step's arithmetic; scalars formed in double).
+// Every trainable element must be the output of exactly one item (gradients written elsewhere: an item with
+// partial == out, splits = 1).  The 16-byte path needs the arenas' bases and every item's offset 16-byte aligned.
+extern "C" int clslam_reduce_multi_adam(const void* items_dev, int nitems, int blocks_per_item, const float* grad_base,
+                                        float* param, float* exp_avg, float* exp_avg_sq, double lr, double beta1, double beta2,
+                                        double eps, int step, const float* guard, void* stream) {
+    CLSLAM_REQUIRE(items_dev && nitems >= 0 && blocks_per_item >= 1 && grad_base && param && exp_avg && exp_avg_sq && step >= 1,
+                   "reduce_multi_adam: bad args");
+    CLSLAM_REQUIRE(((((uintptr_t)grad_base) | ((uintptr_t)param) | ((uintptr_t)exp_avg) | ((uintptr_t)exp_avg_sq)) & 15) == 0,
+                   "reduce_multi_adam: arenas must be 16-byte aligned");
+    if (!nitems) return CLSLAM_OK;
+    AdamArgs ad;
+    ad.g_base = grad_base; ad.p = param; ad.m = exp_avg; ad.v = exp_avg_sq;
+    ad.step_size = (float)(lr / (1.0 - pow(beta1, (double)step)));
+    ad.w1 = (float)(1.0 - beta1); ad.beta2 = (float)beta2; ad.w2 = (float)(1.0 - beta2);
+    ad.bc2_sqrt = (float)sqrt(1.0 - pow(beta2, (double)step)); ad.eps = (float)eps; ad.guard = guard;
+    hipLaunchKernelGGL(reduce_multi_kernel<true>, dim3(blocks_per_item, nitems), dim3(256), 0, (hipStream_t)stream,
+                       (const ReduceItem*)items_dev, ad);
+    return check_launch("reduce_multi_adam");
 }
 
 extern "C" int clslam_colsum_blocks(int rows) { return std::max(1, std::min(512, cdiv(rows, 16))); }

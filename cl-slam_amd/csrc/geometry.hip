@@ -178,8 +178,7 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(const float* __restrict__
                 dPacc[fi * 12 + i * 4 + 2] += dp[i] * X[2];
                 dPacc[fi * 12 + i * 4 + 3] += dp[i];
             }
-            for (int j = 0; j < 3; ++j)
-                ddepth += (Pm[0 * 4 + j] * dp[0] + Pm[1 * 4 + j] * dp[1] + Pm[2 * 4 + j] * dp[2]) * cam[j];
+            ddepth += ddepth_from_duv(Pm, cam, du, dv, 1.f / den);
         }
         float dd;
         if (dmode == 2) dd = -db * dep * dep * ddepth;

@@ -55,6 +55,22 @@ __device__ __forceinline__ Sample sample_coords(float u, float v, int H, int W) 
 }
 
 
+// dL/d depth of one source frame from (du, dv) = dL/d(u, v), the projection row-major Pm (3x4), cam = K^-1 [x, y, 1] and
+// 1/den.  With p = depth * (Pm[:, :3] cam) + Pm[:, 3] and u = p0 / den, den = p2 + 1e-7:
+//     d u / d depth = (a0 * (P23 + 1e-7) - a2 * P03) / den^2,   a = Pm[:, :3] cam      (v alike),
+// i.e. the form in which the `u * du` parts of the chain rule's three terms have cancelled ANALYTICALLY.  Summing the three
+// terms in fp32 (what autograd does) cancels them numerically to ~1e-7 * |u| * |du| -- with this network's small
+// translations that is as large as the result itself at |u| of a few hundred pixels (tests/test_backward_parity.py:
+// isolated pixels off by a factor of two against the float64 oracle).
+__device__ __forceinline__ float ddepth_from_duv(const float* __restrict__ Pm, const float* cam, float du, float dv,
+                                                 float inv_den) {
+    const float a0 = Pm[0] * cam[0] + Pm[1] * cam[1] + Pm[2] * cam[2];
+    const float a1 = Pm[4] * cam[0] + Pm[5] * cam[1] + Pm[6] * cam[2];
+    const float a2 = Pm[8] * cam[0] + Pm[9] * cam[1] + Pm[10] * cam[2];
+    const float p23 = Pm[11] + 1e-7f;
+    return (du * (a0 * p23 - a2 * Pm[3]) + dv * (a1 * p23 - a2 * Pm[7])) * inv_den * inv_den;
+}
+
 // mode/a/b of disp_to_depth_dev from (min_depth, max_depth); values <= 0 stand for None (utils.py:120-142)
 inline void depth_mode(float min_depth, float max_depth, float* a, float* b, int* mode) {
     if (min_depth <= 0.f && max_depth <= 0.f) { *mode = 0; *a = 0.f; *b = 0.f; }

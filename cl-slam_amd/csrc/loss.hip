@@ -334,9 +334,7 @@ __global__ __launch_bounds__(256) void loss_bwd2_kernel(Pyramid pyr, const unsig
                 dPacc[i * 4 + 0] += dp[i] * X[0]; dPacc[i * 4 + 1] += dp[i] * X[1];
                 dPacc[i * 4 + 2] += dp[i] * X[2]; dPacc[i * 4 + 3] += dp[i];
             }
-            float ddepth = 0.f;
-            for (int j = 0; j < 3; ++j)
-                ddepth += (Pm[0 * 4 + j] * dp[0] + Pm[1 * 4 + j] * dp[1] + Pm[2 * 4 + j] * dp[2]) * cam[j];
+            const float ddepth = ddepth_from_duv(Pm, cam, du, dv, inv_den);
             const float dd = (dmode == 2) ? -db * dep * dep * ddepth : -dep / disp * ddepth;
             // frame 0 writes, frame 1 adds (same thread, same address: ordered)
             float* o = ddisp_up + (size_t)b * HW + pi;
@@ -717,8 +715,7 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(Pyramid pyr, const unsign
                     dPacc[12 + i * 4 + 2] += dp[i] * X[2]; dPacc[12 + i * 4 + 3] += dp[i];
                 }
             }
-            for (int j = 0; j < 3; ++j)
-                ddepth += (Pm[0 * 4 + j] * dp[0] + Pm[1 * 4 + j] * dp[1] + Pm[2 * 4 + j] * dp[2]) * cam[j];
+            ddepth += ddepth_from_duv(Pm, cam, du, dv, 1.f / den);
         }
         ddisp_up[(size_t)b * HW + pi] = (dmode == 2) ? -db * dep * dep * ddepth : -dep / disp * ddepth;
     }

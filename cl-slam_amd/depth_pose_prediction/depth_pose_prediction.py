@@ -262,6 +262,7 @@ class DepthPosePrediction:
         self._dp = dict(group=process_group, global_batch=int(global_batch_size), offset=int(shard_offset), dist=dist)
         # overlap the gradient all-reduce + Adam with the next step's (frozen) encoders
         self.engine.async_tail = os.environ.get('CLSLAM_ASYNC_TAIL', '1') != '0'
+        self.engine.data_parallel = True
         self.engine.noise_stream = int(shard_offset)     # identically seeded ranks draw different tie-break fields
 
     def gather_outputs(self, outputs: Dict[Any, Tensor]) -> Dict[Any, Tensor]:
@@ -672,7 +673,8 @@ class DepthPosePrediction:
 
     def _backward(self, inputs: Dict[Any, Tensor]) -> None:
         B = inputs['rgb_aug', 0, 0].shape[0]
-        self.engine.backward(B)
+        # (adapt() calls optimizer.step() right after this: on a single GPU the reduction is fused into that launch)
+        self.engine.backward(B, defer_reduce=self._dp is None)
         self._reduce_gradients()
 
     def _reduce_gradients(self) -> None:

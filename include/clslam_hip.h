@@ -127,6 +127,13 @@ int clslam_reduce_partials(const float* partial, float* out, size_t n, int split
 /* Batched clslam_reduce_partials: items_dev is a DEVICE array of nitems records
  * {const float* partial; float* out; uint64_t n; int32_t splits; float scale} (32 bytes each).     */
 int clslam_reduce_multi(const void* items_dev, int nitems, int blocks_per_item, void* stream);
+/* clslam_reduce_multi followed, element by element, by the optimizer step of clslam_adam_step (torch.optim.Adam.step,
+ * dpp.py:313) -- the single-GPU path, where nothing sits between the reduction and the update.  grad_base / param /
+ * exp_avg / exp_avg_sq: the flat arenas (an item's `out` lies inside grad_base's; the same offset addresses the others);
+ * every trainable element must be the output of exactly one item.  guard: see clslam_adam_step.                       */
+int clslam_reduce_multi_adam(const void* items_dev, int nitems, int blocks_per_item, const float* grad_base, float* param,
+                             float* exp_avg, float* exp_avg_sq, double lr, double beta1, double beta2, double eps, int step,
+                             const float* guard, void* stream);
 /* bias gradient: column sums of x[rows][ch], stage 1 (follow with clslam_reduce_partials).     */
 int clslam_colsum_blocks(int rows);
 int clslam_colsum(const float* x, float* partial, int rows, int ch, void* stream);

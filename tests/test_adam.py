@@ -28,3 +28,39 @@ def test_adam_matches_torch(backend):
     st = opt.state[ref]
     assert rel_err(m.cpu(), st['exp_avg']) < 1e-6
     assert rel_err(v.cpu(), st['exp_avg_sq']) < 1e-6
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_reduction_fused_with_adam_is_bitwise_the_two_launches(backend):
+    """Single-GPU path: clslam_reduce_multi_adam (gradient partials -> gradient arena -> Adam update, one launch) against
+    clslam_reduce_multi followed by clslam_adam_step: identical gradient, weights and moments, bit for bit, over two
+    adaptation steps of the whole predictor; a NaN guard leaves weights and moments alone but still reduces."""
+    dev = use_backend(backend)
+    from clslam_hip import synth
+    from predictor_util import make_predictor
+    H, W, B = 64, 128, 2
+    batch = synth.make_batch(B, H, W, seed=3)
+    res = []
+    for fuse in (True, False):
+        p = make_predictor(H, W, B)
+        p.engine.fuse_adam = fuse
+        p.set_tie_break_noise(synth.make_noise(B, H, W, seed=5))
+        for _ in range(2):
+            _, losses = p.adapt(None, {k: v.clone() for k, v in batch.items()}, steps=1)
+        e = p.engine
+        res.append((e.w.clone(), e.g.clone(), e.m.clone(), e.v.clone(), losses['loss'].clone()))
+    for a, b in zip(res[0], res[1]):
+        assert torch.equal(a, b)
+    # the raw entry point with a NaN guard: gradients reduced, nothing updated
+    n, splits = 1024, 3
+    part = torch.randn(splits, n, generator=torch.Generator().manual_seed(1)).to(dev)
+    g, w = torch.zeros(n, device=dev), torch.ones(n, device=dev)
+    m, v = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    table = ops.make_reduce_table([(part, g, n, splits)], dev)
+    ops.reduce_multi_adam(table, 1, g, w, m, v, 1e-4, 1, guard=torch.full((1,), float('nan'), device=dev))
+    assert torch.equal(g.cpu(), part.cpu()[0] + part.cpu()[1] + part.cpu()[2])
+    assert torch.equal(w.cpu(), torch.ones(n)) and not m.any() and not v.any()
+    ops.reduce_multi_adam(table, 1, g, w, m, v, 1e-4, 1, guard=torch.zeros(1, device=dev))
+    w2, m2, v2 = torch.ones(n, device=dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    ops.adam_step(w2, g, m2, v2, 1e-4, 1)
+    assert torch.equal(w, w2) and torch.equal(m, m2) and torch.equal(v, v2)
