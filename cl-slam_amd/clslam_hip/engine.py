@@ -162,9 +162,12 @@ class Engine:
         # xGMI all-reduce.  Whatever reads trainable state waits on the event (wait_training()).
         self.async_tail = False
         self.data_parallel = False    # set by DepthPosePrediction.enable_data_parallel: an all-reduce sits between reduction and Adam
-        # single-GPU path: the gradient reduction and the optimizer step are ONE launch (clslam_reduce_multi_adam);
-        # backward(defer_reduce=True) leaves the reduction to adam()
-        self.fuse_adam = os.environ.get('CLSLAM_FUSE_ADAM', '1') != '0'
+        # single-GPU path, opt-in (CLSLAM_FUSE_ADAM=1): the gradient reduction and the optimizer step as ONE launch
+        # (clslam_reduce_multi_adam; backward(defer_reduce=True) leaves the reduction to adam()).  Bitwise the two launches
+        # (tests/test_adam.py) but not faster on the MI355X: 3.316 vs 3.311 ms at B = 5, 1.515 vs 1.454 ms at K = 0 -- in the
+        # reduction only one lane in KL (4...64 for the many-split layers) holds a finished sum, so the update's six arena
+        # accesses per element run at a fraction of the Adam kernel's width; the launch saved is worth less than that.
+        self.fuse_adam = os.environ.get('CLSLAM_FUSE_ADAM', '0') == '1'
         self._pending_reduce = None
         self.tail_stream = pool.get('tail')
         self._tail_event = None       # optimizer step in flight on tail_stream
@@ -580,8 +583,11 @@ class Engine:
             id_ready = torch.cuda.Event()
             id_ready.record(wg)
         # the 1x1 downsample convolutions of both encoders go to the wgrad stream (idle during the forward once the identity
-        # maps are out); a captured graph keeps the serial order
-        ds_aux = wg if (os.environ.get('CLSLAM_DS_AUX', '1') != '0' and not self._capturing) else None
+        # maps are out) -- for a single triplet only, where the step is a chain of dependent 5-15 us launches (K = 0, 192x640:
+        # 1.454 -> 1.403 ms per frame incl. read-back).  At B = 5 the chip is throughput-bound and the six fork/join event
+        # pairs cost more than the launches they hide (3.311 -> 3.377 ms): CLSLAM_DS_AUX=1 / 0 forces it on / off.
+        ds_mode = os.environ.get('CLSLAM_DS_AUX', 'auto')
+        ds_aux = wg if ((ds_mode == '1' or (ds_mode == 'auto' and B == 1)) and not self._capturing) else None
         if side is not None:
             main = self._main
             side.wait_stream(main)

@@ -4,7 +4,7 @@
 //   m = m + (g - m)*(1-b1);  v = v*b2 + (1-b2)*g*g;
 //   p = p - (lr/(1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
 // HBM-bound: 4 streams read (p,g,m,v), 3 written, 16-byte accesses.
-#include "common.h"
+#include "adam_dev.h"
 
 namespace clslam {
 
@@ -23,11 +23,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
         float* P = &pp.x; float* G = &gg.x; float* M = &mm.x; float* V = &vv.x;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const float gr = G[k] * grad_scale;
-            M[k] = M[k] + (gr - M[k]) * w1;
-            V[k] = V[k] * beta2 + w2 * gr * gr;
-            const float denom = sqrtf(V[k]) / bc2_sqrt + eps;
-            P[k] = P[k] - step_size * (M[k] / denom);
+            adam_update(P[k], M[k], V[k], G[k] * grad_scale, step_size, w1, beta2, w2, bc2_sqrt, eps);
         }
         reinterpret_cast<float4*>(p)[i] = pp;
         reinterpret_cast<float4*>(m)[i] = mm;
@@ -36,11 +32,9 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     // tail (n not a multiple of 4)
     if (blockIdx.x == 0) {
         for (size_t i = n4 * 4 + threadIdx.x; i < n; i += blockDim.x) {
-            const float gr = g[i] * grad_scale;
-            const float mk = m[i] + (gr - m[i]) * w1;
-            const float vk = v[i] * beta2 + w2 * gr * gr;
-            m[i] = mk; v[i] = vk;
-            p[i] = p[i] - step_size * (mk / (sqrtf(vk) / bc2_sqrt + eps));
+            float pk = p[i], mk = m[i], vk = v[i];
+            adam_update(pk, mk, vk, g[i] * grad_scale, step_size, w1, beta2, w2, bc2_sqrt, eps);
+            p[i] = pk; m[i] = mk; v[i] = vk;
         }
     }
 }

@@ -10,7 +10,7 @@
 //           the pixel index m; split over pixel ranges (deterministic two-stage reduction:
 //           clslam_wgrad writes per-split partials, clslam_reduce_partials sums them in order).
 //   bias  : clslam_colsum (two-stage, deterministic).
-#include "common.h"
+#include "adam_dev.h"
 
 namespace clslam {
 
@@ -383,10 +383,9 @@ struct AdamArgs {
 };
 
 __device__ __forceinline__ void adam_apply(const AdamArgs& a, size_t idx, float gr) {
-    const float mk = a.m[idx] + (gr - a.m[idx]) * a.w1;
-    const float vk = a.v[idx] * a.beta2 + a.w2 * gr * gr;
-    a.m[idx] = mk; a.v[idx] = vk;
-    a.p[idx] = a.p[idx] - a.step_size * (mk / (sqrtf(vk) / a.bc2_sqrt + a.eps));
+    float pk = a.p[idx], mk = a.m[idx], vk = a.v[idx];
+    adam_update(pk, mk, vk, gr, a.step_size, a.w1, a.beta2, a.w2, a.bc2_sqrt, a.eps);
+    a.p[idx] = pk; a.m[idx] = mk; a.v[idx] = vk;
 }
 
 __device__ __forceinline__ void adam_apply4(const AdamArgs& a, size_t idx, const float4& g4) {   // idx: multiple of 4
@@ -394,11 +393,7 @@ __device__ __forceinline__ void adam_apply4(const AdamArgs& a, size_t idx, const
     float* P = &pp.x; float* M = &mm.x; float* V = &vv.x;
     const float G[4] = {g4.x, g4.y, g4.z, g4.w};
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        M[k] = M[k] + (G[k] - M[k]) * a.w1;
-        V[k] = V[k] * a.beta2 + a.w2 * G[k] * G[k];
-        P[k] = P[k] - a.step_size * (M[k] / (sqrtf(V[k]) / a.bc2_sqrt + a.eps));
-    }
+    for (int k = 0; k < 4; ++k) adam_update(P[k], M[k], V[k], G[k], a.step_size, a.w1, a.beta2, a.w2, a.bc2_sqrt, a.eps);
     *reinterpret_cast<float4*>(a.p + idx) = pp; *reinterpret_cast<float4*>(a.m + idx) = mm; *reinterpret_cast<float4*>(a.v + idx) = vv;
 }
 
