@@ -168,6 +168,14 @@ class Engine:
         # reduction only one lane in KL (4...64 for the many-split layers) holds a finished sum, so the update's six arena
         # accesses per element run at a fraction of the Adam kernel's width; the launch saved is worth less than that.
         self.fuse_adam = os.environ.get('CLSLAM_FUSE_ADAM', '0') == '1'
+        # slam.py:143-147 runs models['depth_encoder'](online_image) on every frame BEFORE adapt() /
+        # adapt(online, None), whose own depth-encoder pass over the online sample repeats exactly that computation (frozen
+        # encoder, eval-mode BatchNorm, and the online sample is not augmented: rgb_aug == rgb, datasets/utils.py:25,148-150).
+        # run_encoder() keeps its input and features; a single-triplet forward whose network input has the same CONTENT
+        # takes them instead of re-running the 22 launches of the depth encoder.
+        self.descriptor_memo = os.environ.get('CLSLAM_DESCRIPTOR_MEMO', '1') != '0'
+        self._memo = None
+        self.memo_hits = 0
         self._pending_reduce = None
         self.tail_stream = pool.get('tail')
         self._tail_event = None       # optimizer step in flight on tail_stream
@@ -273,6 +281,7 @@ class Engine:
         for ws in self._ws.values():           # features of the previous encoder weights are void
             if hasattr(ws, 'frozen_valid'):
                 ws.frozen_valid = False
+        self._memo = None
 
     @torch.no_grad()
     def sync_modules(self) -> None:
@@ -541,6 +550,7 @@ class Engine:
         ws = self.workspace(B)
         reuse = bool(reuse_frozen and self.reuse_frozen_features and getattr(ws, 'frozen_valid', False))
         ws.frozen_valid = False
+        memo_feats = self._memo_lookup(aug[0]) if (B == 1 and not reuse) else None
         if train:
             self._train_bufs(ws)
         if self.fresh_outputs:
@@ -604,8 +614,11 @@ class Engine:
                     return pf4
 
             def depth_encoder():
-                return ws.dfeats if reuse else self._encoder(self.enc['depth_encoder'], ws.denc, B, [(aug[0], None, 0, B)],
-                                                             stream=main, aux=ds_aux)
+                if reuse:
+                    return ws.dfeats
+                if memo_feats is not None:
+                    return memo_feats
+                return self._encoder(self.enc['depth_encoder'], ws.denc, B, [(aug[0], None, 0, B)], stream=main, aux=ds_aux)
             # the host enqueues ~50 launches per branch (~0.7 ms): the depth branch is the longer
             # dependency chain (encoder + decoder), so its kernels go out first
             if reuse:                   # no encoders to hide the host's launches behind: the long chain goes out first
@@ -626,7 +639,8 @@ class Engine:
             main.wait_stream(side)
         else:
             self.wait_training()
-            dfeats = ws.dfeats if reuse else self._encoder(self.enc['depth_encoder'], ws.denc, B, [(aug[0], None, 0, B)])
+            dfeats = (ws.dfeats if reuse else memo_feats if memo_feats is not None else
+                      self._encoder(self.enc['depth_encoder'], ws.denc, B, [(aug[0], None, 0, B)]))
             self._depth_decoder(ws, dfeats)
             pf4 = ws.pf4 if reuse else self._encoder(self.enc['pose_encoder'], ws.penc, 2 * B,
                                                      [(aug[-1], aug[0], 0, B), (aug[0], aug[1], B, B)],
@@ -679,6 +693,20 @@ class Engine:
                                  aux=aux if n_smooth else None, B=B, rgb0=rgb0)
         ws.frozen_valid = True      # encoder features + identity maps of THESE inputs and encoder weights are held
         return self._outputs(ws, B), ws.losses
+
+    def _memo_lookup(self, x: torch.Tensor) -> Optional[List[torch.Tensor]]:
+        """Features of the last run_encoder('depth_encoder', ...) call if `x` (1,3,H,W on the device, already complete on the
+        current stream) has the same content and the encoder weights have not been re-packed since.  The comparison is one
+        small kernel + a 1-byte read-back (~30 us) against the ~0.3 ms of launch-bound encoder it replaces; identity cannot
+        be used -- slam.py hands the descriptor pass a device copy and adapt() a host tensor (slam.py:145, 300-309)."""
+        m = self._memo
+        if (m is None or not self.descriptor_memo or self._capturing or m.version != self._packed_version
+                or m.x.shape != x.shape or m.x.device != x.device):
+            return None
+        if not bool(torch.equal(m.x, x)):
+            return None
+        self.memo_hits += 1
+        return m.feats
 
     def _next_noise_draw(self) -> Tuple[int, int]:
         """(Philox key, draw offset) of this forward's tie-break noise.  On the GPU the draw counter IS the device generator's
@@ -1105,6 +1133,11 @@ class Engine:
         else:
             stem = [(x[:, :3].contiguous(), x[:, 3:].contiguous(), 0, n)]
         feats = self._encoder(self.enc[which], bufs, n, stem)
+        self._memo = None
+        if which == 'depth_encoder' and n == 1 and self.descriptor_memo:
+            # (a private copy of the input: the caller owns x and may overwrite it; the feature buffers belong to this
+            # workspace and are only rewritten by the next call of this function, which replaces the memo)
+            self._memo = SimpleNamespace(x=x.clone(), feats=feats, version=self._packed_version)
         return [f.permute(0, 3, 1, 2) for f in feats]
 
     def run_pose(self, image_0: torch.Tensor, image_1: torch.Tensor) -> torch.Tensor:

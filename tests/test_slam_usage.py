@@ -311,3 +311,55 @@ def test_default_outputs_live_on_one_device_in_all_three_modes():
         caller_math(out, batch)
     out, _ = fast.adapt(dict(batch), None)                                      # forward-only calls: device tensors
     assert torch.isfinite(caller_math(out, batch))
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_descriptor_pass_is_memoised_for_the_single_triplet_forward(backend):
+    """SURVEY.md 8(f) rank 2 (slam.py:143-147): the per-frame `models['depth_encoder'](online_image)` pass is kept, and the
+    adapt() / adapt(online, None) / predict() call that follows on the same (un-augmented) online frame takes its features
+    instead of re-running the depth encoder -- bitwise the same outputs, losses and weights; a different image, an input the
+    caller overwrote in place after the descriptor call, or re-packed weights are misses."""
+    dev = use_backend(backend)
+    B = 1
+    batch = synth.make_batch(B, H, W, seed=21)
+    other = synth.make_batch(B, H, W, seed=22)
+    for d in (batch, other):          # the online dataset does not augment (datasets/utils.py:25,148-150): rgb_aug IS rgb
+        for k in list(d):
+            if k[0] == 'rgb_aug':
+                d[k] = d['rgb', k[1], k[2]].clone()
+    noise = synth.make_noise(B, H, W, seed=23)
+    runs = {}
+    for memo in (True, False):
+        p = make_predictor(H, W, B)
+        p.engine.descriptor_memo = memo
+        p.set_tie_break_noise(noise)
+        log = []
+        # frame 1: descriptor, then a training step on the same frame (K = 0)
+        x = batch['rgb', 0, 0].clone().to(dev)
+        feat = p.models['depth_encoder'](x)[4].mean(-1).mean(-1).cpu()
+        x.zero_()                                                     # the caller's tensor is the caller's: must not matter
+        out, losses = p.adapt(dict(batch), dict(batch))
+        log += [feat, out['depth', 0].cpu().clone(), out['cam_T_cam', 0, 1].cpu().clone(), losses['loss'].cpu().clone()]
+        hits1 = p.engine.memo_hits
+        # frame 2: descriptor, then the no-adaptation forward (slam.py:178) and predict() on the same frame
+        p.models['depth_encoder'](other['rgb', 0, 0].to(dev))
+        out, losses = p.adapt(dict(other), None)
+        log += [out['depth', 0].cpu().clone(), losses['loss'].cpu().clone()]
+        log.append(p.predict(dict(other))['depth', 0].cpu().clone())
+        hits2 = p.engine.memo_hits
+        # a descriptor of ANOTHER image does not serve this frame
+        p.models['depth_encoder'](batch['rgb', 0, 0].to(dev))
+        out, _ = p.adapt(dict(other), None)
+        log.append(out['depth', 0].cpu().clone())
+        hits3 = p.engine.memo_hits
+        # re-packed weights void the memo
+        p.models['depth_encoder'](other['rgb', 0, 0].to(dev))
+        p.engine.pack()
+        out, _ = p.adapt(dict(other), None)
+        log.append(out['depth', 0].cpu().clone())
+        p.engine.wait_training()
+        log.append(p.engine.w.cpu().clone())
+        runs[memo] = (log, (hits1, hits2, hits3, p.engine.memo_hits))
+    assert runs[True][1] == (1, 3, 3, 3) and runs[False][1] == (0, 0, 0, 0)
+    for a, b in zip(runs[True][0], runs[False][0]):
+        assert torch.equal(a, b)

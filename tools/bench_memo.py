@@ -60,3 +60,38 @@ b = a.clone()
 print(f'd) device compare + host sync of one 3x{H}x{W} plane: {t(lambda: bool(torch.equal(a, b))):.3f} ms')
 ah, bh = full['rgb', 0, 0][:1].clone(), full['rgb', 0, 0][:1].clone()
 print(f'd) host compare of the same plane: {t(lambda: bool(torch.equal(ah, bh)), n=50):.3f} ms')
+
+# ---- round 3: the frame as slam.py runs it when the replay buffer is off (K = 0) or adaptation is off (slam.py:178) --------
+# descriptor pass (slam.py:143-147) + adapt() on the single online triplet, with and without the descriptor memo
+# (Engine._memo_lookup: the adapt forward takes the descriptor pass's features when its network input has the same content).
+print('--- single-triplet frames, descriptor pass + adapt, memo on / off (ms per frame)')
+one = synth.make_batch(1, H, W, seed=0)
+for k in list(one):
+    if k[0] == 'rgb_aug':
+        one[k] = one['rgb', k[1], k[2]].clone()          # the online dataset does not augment (datasets/utils.py:25)
+host = {k: v.pin_memory() for k, v in one.items()}
+p1 = bench.build_predictor(H, W, 1)
+
+
+def frame(train):
+    online = dict(host)
+    p1._set_eval()
+    with torch.no_grad():
+        x = online['rgb', 0, 0].to(dev)
+        f = p1.models['depth_encoder'](x)[4].detach().mean(-1).mean(-1).cpu().numpy()
+    out, losses = p1.adapt(online, online if train else None)
+    T = out['cam_T_cam', 0, 1][0, :].squeeze().cpu().detach().numpy()
+    return f, T, {k: float(v.squeeze().cpu().detach().numpy()) for k, v in losses.items()}
+
+
+for train in (True, False):
+    res = {}
+    for memo in (False, True, False, True):
+        p1.engine.descriptor_memo = memo
+        h0 = p1.engine.memo_hits
+        ms = t(lambda: frame(train), n=40, warm=8)
+        res.setdefault(memo, []).append(ms)
+        hits = p1.engine.memo_hits - h0
+    off, on = min(res[False]), min(res[True])
+    print(f"{'K=0 adapt(online, online)' if train else 'no adaptation: adapt(online, None)'}: memo off {off:.3f}  on {on:.3f}  "
+          f"({(off - on) / off * 100:.1f} % of the frame; hits in the last run {hits}/48)")
