@@ -575,9 +575,9 @@ class DepthPosePrediction:
         # frame N+1 need not wait for frame N's backward + optimizer step still queued on the caller's stream -- they cross
         # PCIe underneath it.
         users = [cur] + [st for st in (self.engine.side_stream, self.engine.wg_stream) if st is not None]
-        def copy(k):
+        def copy(k, consumers=users):
             t = inputs[k].to(dev, non_blocking=True)
-            for st in users:                # consumed on the engine's streams: keep the block until they are past it
+            for st in consumers:            # consumed on the engine's streams: keep the block until they are past it
                 t.record_stream(st)
             inputs[k] = t
         with torch.cuda.stream(cs):
@@ -596,7 +596,7 @@ class DepthPosePrediction:
             dict_ev = all_ev
             if extra:                        # not read by the step: only the caller's stream is ordered behind them
                 for k in extra:
-                    copy(k)
+                    copy(k, (cur,))          # never read by the engine: only the caller's stream may touch them
                 dict_ev = torch.cuda.Event()
                 dict_ev.record(cs)
         return evs[0], evs[1], evs[2], all_ev, dict_ev
