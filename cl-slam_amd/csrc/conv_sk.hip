@@ -52,6 +52,7 @@ struct SkK {
     long long units;
     float* slabs;        // [G][BM*BN] raw partial tiles
     unsigned* flags;     // [G], zero on entry, reset by the consumer
+    int b_fastest;       // tile order: 1 = the images of one (spatial, channel) tile position are adjacent (see launch_sk)
     unsigned epoch;      // value a producer publishes in this launch (non-zero, different for consecutive eager launches)
     int dbg;             // measurement probes (CLSLAM_SK_DBG): 1 no epilogue, 2 no hand-off, 4 no MFMA, 8 no DMA
 };
@@ -94,16 +95,29 @@ __global__ __launch_bounds__(NWM * NWN * 64) void conv3x3_sk_kernel(SkK p) {
     const int dslot = (lane & 3) ^ (((drow >> 2) & 1) << 1);
     const int wlane_off = drow * 9 * Cin + dslot * 4;             // weight row (n = drow, tap 0) + slot
 
+    // tile index -> (channel tile, spatial tile, image).  Default: the channel tiles of one spatial tile are adjacent (they
+    // share the input patch); b_fastest: the IMAGES of one (channel, spatial) tile are adjacent, so the ~5 consecutive tiles
+    // an XCD's workgroups walk share one 64-channel weight slab through that XCD's L2 instead of each fetching their own
+    // (layers whose weights are larger than their input: the 256/512-channel stages).
+    auto decode_tile = [&](int t, int& tn, int& tx, int& ty, int& b) {
+        if (p.b_fastest) {
+            b = t % p.B; t /= p.B;
+            tn = t % p.tilesN; t /= p.tilesN;
+            tx = t % p.tilesX; ty = t / p.tilesX;
+        } else {
+            tn = t % p.tilesN; t /= p.tilesN;
+            tx = t % p.tilesX; t /= p.tilesX;
+            ty = t % p.tilesY; b = t / p.tilesY;
+        }
+    };
+
     // ---- per-tile state of the DMA cursor ------------------------------------------------------------------
     constexpr int MYP = (NPP + NW - 1) / NW, MYW = (NWP + NW - 1) / NW;
     int offA[MYP], offB[MYP];     // element offsets of this lane's patch rows in src_a / src_b, -1: zero page
     int dma_n0 = 0;
     auto dma_setup_tile = [&](int t) {
-        const int tn = t % p.tilesN;
-        int sp = t / p.tilesN;
-        const int tx = sp % p.tilesX; sp /= p.tilesX;
-        const int ty = sp % p.tilesY;
-        const int b = sp / p.tilesY;
+        int tn, tx, ty, b;
+        decode_tile(t, tn, tx, ty, b);
         dma_n0 = tn * BN;
         const int m0 = tx * BM;
         const int oy0 = RUN ? m0 / p.Wo : ty * TH, ox0 = RUN ? 0 : tx * TW;
@@ -180,8 +194,8 @@ __global__ __launch_bounds__(NWM * NWN * 64) void conv3x3_sk_kernel(SkK p) {
     int c_pw = PW;
     auto cmp_setup_tile = [&](int t) {
         if constexpr (RUN) {
-            int sp = t / p.tilesN;
-            const int tx = sp % p.tilesX;
+            int tn, tx, ty, b;
+            decode_tile(t, tn, tx, ty, b);
             const int m0 = tx * BM;
             const int oy0 = m0 / p.Wo;
             c_pw = p.Wo + 2;
@@ -305,11 +319,8 @@ __global__ __launch_bounds__(NWM * NWN * 64) void conv3x3_sk_kernel(SkK p) {
         if (p.dbg & 1) { if (acc[0][0][0] == 12345.678f) uncounted_flag_store((unsigned*)p.out, 1u); return; }
         // epilogue (scale/shift = folded BatchNorm or bias, residual, activation, activation-gradient mask):
         // this lane's four channels of pixel frow of every MFMA tile, 16-byte accesses
-        const int tn = t % p.tilesN;
-        int sp = t / p.tilesN;
-        const int tx = sp % p.tilesX; sp /= p.tilesX;
-        const int ty = sp % p.tilesY;
-        const int b = sp / p.tilesY;
+        int tn, tx, ty, b;
+        decode_tile(t, tn, tx, ty, b);
         const int n0 = tn * BN, m0 = tx * BM;
         const int oy0 = RUN ? 0 : ty * TH, ox0 = RUN ? 0 : tx * TW;
         size_t opix[TM];
@@ -454,6 +465,9 @@ static int launch_sk(SkK k, const clslam_conv_desc* d, hipStream_t stream) {
     k.tiles = k.tilesX * k.tilesY * k.tilesN * k.B;
     k.NC = (k.Ca + k.Cb) / 16;
     k.units = (long long)k.tiles * k.NC;
+    // weights larger than the layer's input: order the tiles so that an XCD's L2 is shared through the weight slab
+    k.b_fastest = ((size_t)k.Cout * 9 * (k.Ca + k.Cb) > (size_t)k.B * k.Hi * k.Wi * (k.Ca + k.Cb)) ? 1 : 0;
+    if (const char* e = getenv("CLSLAM_SK_B_FASTEST")) k.b_fastest = atoi(e);
     // persistent workgroups: as many per CU as their LDS stages allow (two or three 256-thread groups run their
     // DMA-issue / epilogue / hand-off phases against each other's MFMAs; one 512-thread group has the CU to itself)
     constexpr int PHs = (TH - 1) * S + 3, PWs = (TW - 1) * S + 3;
@@ -495,7 +509,7 @@ int conv3x3_sk_dispatch(const clslam_conv_desc* d, int cfg, hipStream_t stream) 
     k.B = d->batch; k.Hi = d->in_h; k.Wi = d->in_w; k.Ca = d->ch_a; k.Cb = d->ch_b; k.Ho = d->out_h; k.Wo = d->out_w;
     k.Cout = d->ch_out; k.pad = d->pad; k.pad_mode = d->pad_mode; k.ups = d->upsample_a; k.act = d->act;
     k.tilesX = k.tilesY = k.tilesN = k.tiles = k.NC = k.G = 0; k.units = 0; k.slabs = nullptr; k.flags = nullptr;
-    k.epoch = 1u;
+    k.epoch = 1u; k.b_fastest = 0;
     k.dbg = 0;
     if (const char* e = getenv("CLSLAM_SK_DBG")) k.dbg = atoi(e);
     const bool s2 = st == 2;
