@@ -285,7 +285,12 @@ extern "C" int clslam_conv2d_pick_config(const clslam_conv_desc* d) {
         if (d->out_w <= 44 && Cin >= 256 && !tie_case) sk = units128 >= 1280 ? 32 : 33;
         else if (d->out_w <= 84 && d->out_w > 44 && Cin >= 256 && M >= 4000) sk = 30;
     }
-    if (sk_ok && sk_fill && d->stride == 2 && d->out_w <= 24 && Cin >= 256) sk = 30;
+    if (sk_ok && sk_fill && d->stride == 2 && d->out_w <= 24 && Cin >= 256) {
+        // the last stage entry (256 -> 512, 12x40 -> 6x20): 8x16 rectangles cover a 6x20 image with 8x32 pixels (47 % real);
+        // one 128-pixel stride-2 RUN covers it with 94 % (config 32 with stride 2) when its 13 x 41 input band fits the stage
+        const int spanned = std::min(d->out_h, (127 + d->out_w - 1) / d->out_w + 1);
+        sk = (((spanned - 1) * 2 + 3) * ((d->out_w - 1) * 2 + 3) <= 544 && !getenv("CLSLAM_NO_SK_RUN_S2")) ? 32 : 30;
+    }
     // the pose encoder's layer2.0 (64 -> 128, stride 2, 2B images): 74.7 vs 66.2 TFLOP/s; at B = 5 (M = 9600) the tiled kernel wins
     if (sk_ok && sk_fill && d->stride == 2 && d->out_w > 24 && d->out_w <= 84 && M >= 16000) sk = 30;
     if (sk && full_enough(sk)) return sk;

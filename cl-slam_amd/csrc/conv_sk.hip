@@ -57,7 +57,9 @@ struct SkK {
     int dbg;             // measurement probes (CLSLAM_SK_DBG): 1 no epilogue, 2 no hand-off, 4 no MFMA, 8 no DMA
 };
 
-constexpr int sk_run_pp(int bm) { return bm <= 64 ? 336 : 416; }
+// patch rows (pixels) reserved per LDS stage for run tiles; stride-2 runs (the 6x20 outputs of the last stage entry: one
+// 128-pixel run covers a whole 120-pixel image, 13 x 41 input pixels) need the larger band
+constexpr int sk_run_pp(int bm, int s = 1) { return s == 2 ? 544 : (bm <= 64 ? 336 : 416); }
 
 // TH x TW output pixels (RUN: a run of TH*TW row-major pixels of one image), BN output channels, stride S,
 // NWM x NWN waves of TM x TN 16x16 MFMA tiles.
@@ -67,10 +69,10 @@ __global__ __launch_bounds__(NWM * NWN * 64) void conv3x3_sk_kernel(SkK p) {
     constexpr int BM = TH * TW;
     constexpr int TM = BM / (16 * NWM), TN = BN / (16 * NWN);
     constexpr int PH = (TH - 1) * S + 3, PW = (TW - 1) * S + 3;
-    constexpr int PP = RUN ? sk_run_pp(BM) : (PH * PW + 15) / 16 * 16;
+    constexpr int PP = RUN ? sk_run_pp(BM, S) : (PH * PW + 15) / 16 * 16;
     constexpr int NPP = PP / 16, NWP = 9 * BN / 16;              // DMA pieces (1 KiB = 16 rows) per unit
     constexpr int STAGE = (PP + 9 * BN) * 16;                    // floats per LDS stage
-    static_assert(BM % (16 * NWM) == 0 && BN % (16 * NWN) == 0 && TW % 16 == 0 && (!RUN || S == 1), "tile shape");
+    static_assert(BM % (16 * NWM) == 0 && BN % (16 * NWN) == 0 && TW % 16 == 0, "tile shape");
 
     __shared__ __attribute__((aligned(1024))) float lds[2 * STAGE];
     __shared__ int s_flag_ok;
@@ -121,8 +123,8 @@ __global__ __launch_bounds__(NWM * NWN * 64) void conv3x3_sk_kernel(SkK p) {
         dma_n0 = tn * BN;
         const int m0 = tx * BM;
         const int oy0 = RUN ? m0 / p.Wo : ty * TH, ox0 = RUN ? 0 : tx * TW;
-        const int pw = RUN ? p.Wo + 2 : PW;
-        const int ph = RUN ? (min(p.Ho * p.Wo, m0 + BM) - 1) / p.Wo - oy0 + 3 : PH;
+        const int pw = RUN ? (p.Wo - 1) * S + 3 : PW;
+        const int ph = RUN ? ((min(p.Ho * p.Wo, m0 + BM) - 1) / p.Wo - oy0) * S + 3 : PH;
 #pragma unroll
         for (int k = 0; k < MYP; ++k) {
             const int piece = wave + k * NW;
@@ -198,11 +200,11 @@ __global__ __launch_bounds__(NWM * NWN * 64) void conv3x3_sk_kernel(SkK p) {
             decode_tile(t, tn, tx, ty, b);
             const int m0 = tx * BM;
             const int oy0 = m0 / p.Wo;
-            c_pw = p.Wo + 2;
+            c_pw = (p.Wo - 1) * S + 3;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int mm = min(m0 + (wm * TM + i) * 16 + frow, p.Ho * p.Wo - 1);
-                prow[i] = (mm / p.Wo - oy0) * c_pw + (mm % p.Wo);
+                prow[i] = (mm / p.Wo - oy0) * S * c_pw + (mm % p.Wo) * S;
             }
         } else {
 #pragma unroll
@@ -457,7 +459,7 @@ static int launch_sk(SkK k, const clslam_conv_desc* d, hipStream_t stream) {
     constexpr int BM = TH * TW;
     if (RUN) {
         const int spanned = std::min(k.Ho, (BM - 1 + k.Wo - 1) / k.Wo + 1);
-        if ((spanned + 2) * (k.Wo + 2) > sk_run_pp(BM)) { set_error("conv2d: image too wide for stream-K run tiles (Wo=%d)", k.Wo); return CLSLAM_ERR_INVALID; }
+        if (((spanned - 1) * S + 3) * ((k.Wo - 1) * S + 3) > sk_run_pp(BM, S)) { set_error("conv2d: image too wide for stream-K run tiles (Wo=%d, stride %d)", k.Wo, S); return CLSLAM_ERR_INVALID; }
     }
     k.tilesX = RUN ? cdiv(k.Ho * k.Wo, BM) : cdiv(k.Wo, TW);
     k.tilesY = RUN ? 1 : cdiv(k.Ho, TH);
@@ -471,7 +473,7 @@ static int launch_sk(SkK k, const clslam_conv_desc* d, hipStream_t stream) {
     // persistent workgroups: as many per CU as their LDS stages allow (two or three 256-thread groups run their
     // DMA-issue / epilogue / hand-off phases against each other's MFMAs; one 512-thread group has the CU to itself)
     constexpr int PHs = (TH - 1) * S + 3, PWs = (TW - 1) * S + 3;
-    constexpr int PPs = RUN ? sk_run_pp(BM) : (PHs * PWs + 15) / 16 * 16;
+    constexpr int PPs = RUN ? sk_run_pp(BM, S) : (PHs * PWs + 15) / 16 * 16;
     constexpr size_t lds_bytes = (size_t)2 * (PPs + 9 * BN) * 64 + 16;
     constexpr int per_cu = (int)std::max<size_t>(1, std::min<size_t>((size_t)(163840 / lds_bytes), (size_t)(2048 / (NWM * NWN * 64))));
     // (every workgroup must be co-resident: a consumer spins on lower-indexed producers; per_cu is the LDS / thread limit)
@@ -516,7 +518,7 @@ int conv3x3_sk_dispatch(const clslam_conv_desc* d, int cfg, hipStream_t stream) 
     switch (cfg) {
         case 30: return s2 ? launch_sk<8, 16, false, 2, 64, 4, 2>(k, d, stream) : launch_sk<8, 16, false, 1, 64, 4, 2>(k, d, stream);
         case 31: return s2 ? launch_sk<4, 16, false, 2, 64, 4, 2>(k, d, stream) : launch_sk<4, 16, false, 1, 64, 4, 2>(k, d, stream);
-        case 32: if (s2) break; return launch_sk<8, 16, true, 1, 64, 4, 2>(k, d, stream);
+        case 32: return s2 ? launch_sk<8, 16, true, 2, 64, 4, 2>(k, d, stream) : launch_sk<8, 16, true, 1, 64, 4, 2>(k, d, stream);
         case 33: if (s2) break; return launch_sk<4, 16, true, 1, 64, 4, 2>(k, d, stream);
         // 256-thread groups, 32 output channels: two or three groups per CU
         case 34: return s2 ? launch_sk<8, 16, false, 2, 32, 4, 1>(k, d, stream) : launch_sk<8, 16, false, 1, 32, 4, 1>(k, d, stream);

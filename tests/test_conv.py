@@ -157,6 +157,9 @@ STREAMK_CASES = [
     (1, 6, 20, 256, 0, 64, 1, 0, False, 1, False, 33, 16),     # ONE tile pair shared by 16 groups (B=1 regime)
     (2, 12, 40, 32, 0, 64, 2, 0, False, 1, False, 30, 3),      # stride 2
     (1, 9, 21, 32, 0, 64, 2, 0, False, 1, True, 31, 5),        # stride 2, odd sizes
+    (2, 12, 40, 32, 0, 64, 2, 0, False, 1, True, 32, 5),       # stride-2 RUN tiles: a 6x20 output image is one 128-px run
+    (3, 11, 37, 32, 0, 128, 2, 0, False, 1, False, 32, 4),     # ... odd input sizes (6x19 outputs), two channel tiles
+    (1, 8, 12, 16, 0, 64, 2, 0, False, 0, False, 32, 2),       # ... a 4x6 output: several rows per run, mostly padding
     (1, 14, 44, 32, 0, 64, 1, 0, False, 0, False, 30, 11),     # dgrad-like padded domain (pad = 2 below)
     (2, 2, 4, 32, 0, 16, 1, 1, False, 2, False, 33, 3),        # tiny image, reflect
     # 256-thread groups x 32 channels (several groups per CU)
