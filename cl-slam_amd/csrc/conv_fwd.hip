@@ -287,9 +287,14 @@ extern "C" int clslam_conv2d_pick_config(const clslam_conv_desc* d) {
     }
     if (sk_ok && sk_fill && d->stride == 2 && d->out_w <= 24 && Cin >= 256) {
         // the last stage entry (256 -> 512, 12x40 -> 6x20): 8x16 rectangles cover a 6x20 image with 8x32 pixels (47 % real);
-        // one 128-pixel stride-2 RUN covers it with 94 % (config 32 with stride 2) when its 13 x 41 input band fits the stage
+        // one 128-pixel stride-2 RUN covers it with 94 % (config 32 with stride 2) when its 13 x 41 input band fits the stage.
+        // Measured (MI355X, tools/bench_conv.py): B = 5: 45.0 vs 37.1 TFLOP/s, 2B = 10: 66.1 vs 42.6, step 3.32 -> 3.27 ms;
+        // a single triplet has too few (tile, chunk) units for 128-pixel tiles (13.7 vs 19.3 for the 4x16 rectangles, config 31).
         const int spanned = std::min(d->out_h, (127 + d->out_w - 1) / d->out_w + 1);
-        sk = (((spanned - 1) * 2 + 3) * ((d->out_w - 1) * 2 + 3) <= 544 && !getenv("CLSLAM_NO_SK_RUN_S2")) ? 32 : 30;
+        const bool band_fits = ((spanned - 1) * 2 + 3) * ((d->out_w - 1) * 2 + 3) <= 544;
+        const long long units = (long long)d->batch * cdiv(px, 128) * cdiv(d->ch_out, 64) * (Cin / 16);
+        if (units >= 512) sk = (band_fits && !getenv("CLSLAM_NO_SK_RUN_S2")) ? 32 : 30;
+        else sk = 31;
     }
     // the pose encoder's layer2.0 (64 -> 128, stride 2, 2B images): 74.7 vs 66.2 TFLOP/s; at B = 5 (M = 9600) the tiled kernel wins
     if (sk_ok && sk_fill && d->stride == 2 && d->out_w > 24 && d->out_w <= 84 && M >= 16000) sk = 30;
