@@ -302,6 +302,21 @@ extern "C" int clslam_conv2d_pick_config(const clslam_conv_desc* d) {
     if (d->ksize == 3 && d->stride == 1 && d->out_h == d->in_h + 2 * d->pad - 2 && d->out_w == d->in_w + 2 * d->pad - 2) {
         if (d->out_w <= 24) return 22;                         // narrow images: run tiles
         // (config 26, 4x8 px x 32 ch tiles without overhang on 12x40, measured 67 vs 69 TFLOP/s for config 21: not picked)
+        // 8x16 (config 20) or 4x16 (config 21) pixel tiles.  Round 2 chose by M alone (>= 16000: 20).  Measured per shape in
+        // round 3 (tools/bench_conv.py incl. BENCH_DGRAD=1, B = 1 / 5 / 10): what decides is (a) how much of the tile grid is
+        // real pixels -- the padded dgrad domains are 14x42, 26x82, 50x162: 4-row tiles cover 50x162 with 88 % against 82 %
+        // (+8.6 %) -- and (b) whether the 8x16 grid has enough workgroups for 1280 slots: 600 of them lose 9-12 % to 1200
+        // 4x16 ones (128 -> 128 @24x80 at B = 5, 64 -> 32 @48x160, 128 -> 64 @24x80 at 2B), while on the small 14x42 domains at
+        // B >= 5 the larger tile wins by 7-11 % at equal coverage.
+        static const bool pick_v2 = !getenv("CLSLAM_PICK_V1");
+        if (pick_v2 && d->ch_out >= 32) {
+            const double cov20 = (double)px / ((double)cdiv(d->out_h, 8) * 8 * cdiv(d->out_w, 16) * 16);
+            const double cov21 = (double)px / ((double)cdiv(d->out_h, 4) * 4 * cdiv(d->out_w, 16) * 16);
+            const long long nblk20 = (long long)d->batch * cdiv(d->out_h, 8) * cdiv(d->out_w, 16) * cdiv(d->ch_out, 16);
+            if (cov21 > 1.04 * cov20) return 21;
+            if (M >= 4000) return nblk20 < 1000 ? 21 : 20;
+            return nblk20 >= 400 ? 20 : 21;
+        }
         return M >= 16000 ? 20 : 21;                           // 20/21/22 = 12/17/18 with conflict-free LDS rows (24x80 at 2B: 91.5 vs 88.4)
     }
     if (d->ksize == 3 && d->stride == 2 && d->out_h == (d->in_h + 2 * d->pad - 3) / 2 + 1 && d->out_w == (d->in_w + 2 * d->pad - 3) / 2 + 1)

@@ -39,6 +39,20 @@ LAYERS = [
 ]
 
 
+# data-gradient convolutions of the depth decoder: flipped weights on the padded domain (pad = 2: the output is (H+2) x (W+2))
+DGRAD_LAYERS = [
+    ('dgrad 256->256 @12x40 pad2', 1, 12, 40, 256, 0, 256, 3, 1, 0, 0, 2),
+    ('dgrad 128->256 @12x40 pad2', 1, 12, 40, 128, 0, 256, 3, 1, 0, 0, 2),
+    ('dgrad 128->128 @24x80 pad2', 1, 24, 80, 128, 0, 128, 3, 1, 0, 0, 2),
+    ('dgrad 64->128 @24x80 pad2', 1, 24, 80, 64, 0, 128, 3, 1, 0, 0, 2),
+    ('dgrad 64->64 @48x160 pad2', 1, 48, 160, 64, 0, 64, 3, 1, 0, 0, 2),
+    ('dgrad 32->64 @48x160 pad2', 1, 48, 160, 32, 0, 64, 3, 1, 0, 0, 2),
+    ('dgrad 256->256 @6x20 pose 2B', 2, 6, 20, 256, 0, 256, 3, 1, 0, 0, 1),
+]
+if __import__('os').environ.get('BENCH_DGRAD'):
+    LAYERS = DGRAD_LAYERS
+
+
 def timeit(fn, iters=20):
     for _ in range(3):
         fn()
@@ -55,13 +69,14 @@ def timeit(fn, iters=20):
 _sel = __import__('os').environ.get('BENCH_LAYERS')
 if _sel:
     LAYERS = [LAYERS[int(i)] for i in _sel.split(',')]
-for name, bm, Hi, Wi, Ca, Cb, Cout, k, stride, refl, ups in LAYERS:
+for name, bm, Hi, Wi, Ca, Cb, Cout, k, stride, refl, ups, *rest in LAYERS:
+    pad = rest[0] if rest else k // 2
     Bn = B * bm
     Ha, Wa = (Hi // 2, Wi // 2) if ups else (Hi, Wi)
     xa = torch.randn(Bn, Ha, Wa, Ca, device=dev)
     xb = torch.randn(Bn, Hi, Wi, Cb, device=dev) if Cb else None
     w = torch.randn(Cout, k * k, Ca + Cb, device=dev) * 0.05
-    Ho, Wo = (Hi - 1) // stride + 1, (Wi - 1) // stride + 1
+    Ho, Wo = (Hi + 2 * pad - k) // stride + 1, (Wi + 2 * pad - k) // stride + 1
     out = torch.empty(Bn, Ho, Wo, Cout, device=dev)
     flops = 2.0 * Bn * Ho * Wo * Cout * k * k * (Ca + Cb)
     line = f'{name:32s} M={Bn*Ho*Wo:7d} {flops/1e9:7.2f} GF |'
@@ -71,7 +86,7 @@ for name, bm, Hi, Wi, Ca, Cb, Cout, k, stride, refl, ups in LAYERS:
     for cfg in cfgs:
         try:
             ws_arg = wsk if cfg >= 30 else None       # stream-K configs need the zero-filled scratch
-            t = timeit(lambda: ops.conv2d(xa, w, out, src_b=xb, ksize=k, stride=stride, pad_mode=refl, upsample_a=bool(ups),
+            t = timeit(lambda: ops.conv2d(xa, w, out, src_b=xb, ksize=k, stride=stride, pad=pad, pad_mode=refl, upsample_a=bool(ups),
                                           act=1, config=cfg, workspace=ws_arg))
             line += f' c{cfg}:{flops/t/1e12:6.1f}'
             if cfg == -1:
@@ -86,7 +101,7 @@ for name, bm, Hi, Wi, Ca, Cb, Cout, k, stride, refl, ups in LAYERS:
                 line += f' splitK:{flops/t/1e12:6.1f}'
         except Exception:
             line += f' c{cfg}:   -  '
-    if not WGRAD:
+    if not WGRAD or rest:
         print(line, flush=True)
         continue
     # wgrad

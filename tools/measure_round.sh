@@ -8,8 +8,12 @@ TAG=${1:-rXX}
 OUT=$PWD/gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
+# identity of the kernel sources every file of this set was measured on (bench.py prints the same id and refuses to pair
+# its timings with counter files of another build)
+python -c "import sys; sys.path.insert(0, 'cl-slam_amd'); from clslam_hip import _lib; print(_lib.build_id())" 2>/dev/null | tail -1 > $OUT/${TAG}_build_id.txt
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/${TAG}_smoke.txt 2>&1
-python bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
+python bench.py --dump-convs > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
+grep "^# conv" $OUT/${TAG}_bench.err > $OUT/${TAG}_conv_launches.txt
 prof() {   # name, env..., then bench args after --
     local name=$1; shift
     rm -rf /tmp/prof_$name
@@ -39,5 +43,8 @@ BENCH_WGRAD=1 python tools/bench_conv.py 5 30,31,32,33 > $OUT/${TAG}_conv_microb
 BENCH_WGRAD=0 python tools/bench_conv.py 1 30,31,32,33 > $OUT/${TAG}_conv_microbench_b1.txt 2>&1
 python tools/bench_small.py > $OUT/${TAG}_small_kernels.txt 2>&1
 python tools/bench_reduce.py > $OUT/${TAG}_reduce.txt 2>&1
+BENCH_DGRAD=1 BENCH_WGRAD=0 python tools/bench_conv.py 5 20,21,22,26,30,31,32,33 2>&1 | grep -v amdgpu > $OUT/${TAG}_conv_microbench_dgrad.txt
 python tools/bench_gpu_bound.py 2>&1 | grep 'K=' > $OUT/${TAG}_gpu_bound.txt
+python tools/bench_memo.py 2>&1 | grep -v amdgpu > $OUT/${TAG}_descriptor_memo.txt
+bash tools/dp2_gloo.sh > $OUT/${TAG}_dp2_gloo.txt 2>&1
 echo done
