@@ -83,17 +83,16 @@ __global__ __launch_bounds__(256) void warp_fwd_kernel(Pyramid pyr, const float*
     (depth_all + ((size_t)sc * B + b) * HW)[pix] = dep;
     const float* Ki = Kinv + (size_t)b * 16;
     const float fx = (float)x, fy = (float)y;
-    float X[3];
-    for (int i = 0; i < 3; ++i) X[i] = dep * (Ki[i * 4 + 0] * fx + Ki[i * 4 + 1] * fy + Ki[i * 4 + 2]);
+    float X[3], cam[3];
+    backproject_px(Ki, fx, fy, dep, cam, X);
     // The 12 bilinear taps of a frame are loaded unconditionally from clamped addresses and out-of-image taps get weight 0
     // (adding 0 leaves the sum bit-identical): with `if (x1ok) v += pl[..]` every tap was a branch + a load + a wait.
 #pragma unroll
     for (int fi = 0; fi < 2; ++fi) {
         const float* Pm = P + ((size_t)fi * B + b) * 12;
-        float p[3];
-        for (int i = 0; i < 3; ++i) p[i] = Pm[i * 4 + 0] * X[0] + Pm[i * 4 + 1] * X[1] + Pm[i * 4 + 2] * X[2] + Pm[i * 4 + 3];
-        const float den = p[2] + 1e-7f;
-        const Sample s = sample_coords(p[0] / den, p[1] / den, H, W);
+        float u, v, den;
+        project_px(Pm, X, u, v, den);
+        const Sample s = sample_coords(u, v, H, W);
         const float wx1 = s.ix - (float)s.x0, wy1 = s.iy - (float)s.y0;
         const float wx0 = (float)(s.x0 + 1) - s.ix, wy0 = (float)(s.y0 + 1) - s.iy;
         const bool x1ok = s.x0 + 1 < W, y1ok = s.y0 + 1 < H;
@@ -143,14 +142,12 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(const float* __restrict__
         const float dep = disp_to_depth_dev(disp, da, db, dmode);
         const float fx = (float)x, fy = (float)y;
         float cam[3], X[3];
-        for (int i = 0; i < 3; ++i) { cam[i] = Ki[i * 4 + 0] * fx + Ki[i * 4 + 1] * fy + Ki[i * 4 + 2]; X[i] = dep * cam[i]; }
+        backproject_px(Ki, fx, fy, dep, cam, X);
         float ddepth = 0.f;
         for (int fi = 0; fi < 2; ++fi) {
             const float* Pm = P + ((size_t)fi * B + b) * 12;
-            float p[3];
-            for (int i = 0; i < 3; ++i) p[i] = Pm[i * 4 + 0] * X[0] + Pm[i * 4 + 1] * X[1] + Pm[i * 4 + 2] * X[2] + Pm[i * 4 + 3];
-            const float den = p[2] + 1e-7f;
-            const float u = p[0] / den, v = p[1] / den;
+            float u, v, den;
+            project_px(Pm, X, u, v, den);
             const Sample s = sample_coords(u, v, H, W);
             const float wx1 = s.ix - (float)s.x0, wy1 = s.iy - (float)s.y0;
             const float wx0 = (float)(s.x0 + 1) - s.ix, wy0 = (float)(s.y0 + 1) - s.iy;
@@ -356,7 +353,6 @@ extern "C" int clslam_warp_fwd_pyramid(const float* const* disp, const float* sr
 // path uses for every (scale, source frame, sample, pixel), packed as x0 | y0 << 12 | (mx != 0) << 24 | (my != 0) << 25.
 // The same expressions, in the same order, as warp_fwd_kernel / the loss backward: the oracle is re-run on exactly these
 // cells to attribute the part of the gradient residual that comes from samples landing on the other side of a kink.
-template <int VARIANT>   // 0: the expression order of warp_fwd_kernel, 1: that of the loss backward (loss.hip)
 __global__ __launch_bounds__(256) void warp_cells_kernel(Pyramid pyr, const float* __restrict__ Kinv,
                                                          const float* __restrict__ P, int* __restrict__ cells, int B, int H,
                                                          int W, float da, float db, int dmode, int tilesX) {
@@ -372,18 +368,12 @@ __global__ __launch_bounds__(256) void warp_cells_kernel(Pyramid pyr, const floa
     const float* Ki = Kinv + (size_t)b * 16;
     const float fx = (float)x, fy = (float)y;
     float X[3], cam[3];
-    if (VARIANT == 0) {
-        for (int i = 0; i < 3; ++i) X[i] = dep * (Ki[i * 4 + 0] * fx + Ki[i * 4 + 1] * fy + Ki[i * 4 + 2]);
-    } else {
-        for (int i = 0; i < 3; ++i) { cam[i] = Ki[i * 4 + 0] * fx + Ki[i * 4 + 1] * fy + Ki[i * 4 + 2]; X[i] = dep * cam[i]; }
-    }
+    backproject_px(Ki, fx, fy, dep, cam, X);
 #pragma unroll
     for (int fi = 0; fi < 2; ++fi) {
         const float* Pm = P + ((size_t)fi * B + b) * 12;
-        float p[3];
-        for (int i = 0; i < 3; ++i) p[i] = Pm[i * 4 + 0] * X[0] + Pm[i * 4 + 1] * X[1] + Pm[i * 4 + 2] * X[2] + Pm[i * 4 + 3];
-        const float den = p[2] + 1e-7f;
-        const float u = p[0] / den, v = p[1] / den;
+        float u, v, den;
+        project_px(Pm, X, u, v, den);
         const Sample s = sample_coords(u, v, H, W);
         (cells + (((size_t)sc * 2 + fi) * B + b) * HW)[pix] =
             s.x0 | (s.y0 << 12) | ((s.mx != 0.f ? 1 : 0) << 24) | ((s.my != 0.f ? 1 : 0) << 25);
@@ -402,12 +392,8 @@ extern "C" int clslam_warp_cells_pyramid(const float* const* disp, const float* 
     for (int k = 0; k < 4; ++k) { pyr.disp[k] = disp[k]; pyr.h[k] = H >> k; pyr.w[k] = W >> k; }
     if (!batch) return CLSLAM_OK;
     const int tilesX = cdiv(W, WF_TW);
-    if (getenv("CLSLAM_CELLS_VARIANT") && atoi(getenv("CLSLAM_CELLS_VARIANT")) == 1)
-        hipLaunchKernelGGL(warp_cells_kernel<1>, dim3(tilesX * cdiv(H, WF_TH), batch, 4), dim3(256), 0, (hipStream_t)stream, pyr,
-                           inv_k, proj, cells, batch, H, W, a, b, mode, tilesX);
-    else
-        hipLaunchKernelGGL(warp_cells_kernel<0>, dim3(tilesX * cdiv(H, WF_TH), batch, 4), dim3(256), 0, (hipStream_t)stream, pyr,
-                           inv_k, proj, cells, batch, H, W, a, b, mode, tilesX);
+    hipLaunchKernelGGL(warp_cells_kernel, dim3(tilesX * cdiv(H, WF_TH), batch, 4), dim3(256), 0, (hipStream_t)stream, pyr, inv_k,
+                       proj, cells, batch, H, W, a, b, mode, tilesX);
     return check_launch("warp_cells_pyramid");
 }
 

@@ -13,7 +13,14 @@ struct Pyramid {
     int n;
 };
 
+// EVERY function between a disparity and a bilinear cell below has floating-point contraction switched off.  The forward
+// (warp_fwd), the loss backward and the diagnostic read-out each re-derive the sampling position of a pixel, and the
+// backward differentiates the cell the forward sampled: the three must agree to the BIT.  With hipcc free to fuse a
+// multiply-add in one kernel and not in another they did not -- for a sample within one ulp of a cell boundary
+// (u = 447.99998) the backward floored to the next cell and differentiated the wrong pair of pixels: two isolated pixels per
+// scale at 192x640, B = 5, each off by about its own magnitude (tools/diag_bwd.py).
 __device__ __forceinline__ float upsample_disp(const float* __restrict__ d, int h, int w, int H, int W, int y, int x) {
+#pragma clang fp contract(off)
     // F.interpolate(..., mode='bilinear', align_corners=False): src = (dst+0.5)*in/out - 0.5, clamped at 0
     const float ry = (float)h / (float)H, rx = (float)w / (float)W;
     float sy = ry * ((float)y + 0.5f) - 0.5f; if (sy < 0.f) sy = 0.f;
@@ -26,6 +33,7 @@ __device__ __forceinline__ float upsample_disp(const float* __restrict__ d, int 
 }
 
 __device__ __forceinline__ float disp_to_depth_dev(float disp, float dmin_a, float dmin_b, int mode) {
+#pragma clang fp contract(off)
     // mode 0: 1/disp; 1: min_depth/disp (a = min_depth); 2: 1/(a + b*disp) (a = 1/max, b = 1/min - 1/max)
     if (mode == 0) return 1.f / disp;
     if (mode == 1) return dmin_a / disp;
@@ -39,6 +47,7 @@ struct Sample {
 };
 
 __device__ __forceinline__ Sample sample_coords(float u, float v, int H, int W) {
+#pragma clang fp contract(off)
     // Project3D normalisation (layers.py:101-103) followed by grid_sample's un-normalisation
     // (align_corners=True) and border clipping.
     Sample s;
@@ -54,6 +63,24 @@ __device__ __forceinline__ Sample sample_coords(float u, float v, int H, int W) 
     return s;
 }
 
+
+// cam = K^-1 [x, y, 1]^T (row-major 4x4 Ki), X = depth * cam
+__device__ __forceinline__ void backproject_px(const float* __restrict__ Ki, float fx, float fy, float dep, float* cam, float* X) {
+#pragma clang fp contract(off)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { cam[i] = Ki[i * 4 + 0] * fx + Ki[i * 4 + 1] * fy + Ki[i * 4 + 2]; X[i] = dep * cam[i]; }
+}
+
+// p = Pm[:, :3] X + Pm[:, 3] (row-major 3x4), den = p2 + 1e-7, (u, v) = (p0, p1) / den  (layers.py:93-104)
+__device__ __forceinline__ void project_px(const float* __restrict__ Pm, const float* X, float& u, float& v, float& den) {
+#pragma clang fp contract(off)
+    float p[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) p[i] = Pm[i * 4 + 0] * X[0] + Pm[i * 4 + 1] * X[1] + Pm[i * 4 + 2] * X[2] + Pm[i * 4 + 3];
+    den = p[2] + 1e-7f;
+    u = p[0] / den;
+    v = p[1] / den;
+}
 
 // dL/d depth of one source frame from (du, dv) = dL/d(u, v), the projection row-major Pm (3x4), cam = K^-1 [x, y, 1] and
 // 1/den.  With p = depth * (Pm[:, :3] cam) + Pm[:, 3] and u = p0 / den, den = p2 + 1e-7:

@@ -300,11 +300,9 @@ __global__ __launch_bounds__(256) void loss_bwd2_kernel(Pyramid pyr, const unsig
             const float dep = disp_to_depth_dev(disp, da, db, dmode);
             const float fx = (float)x, fy = (float)y;
             float cam[3], X[3];
-            for (int i = 0; i < 3; ++i) { cam[i] = Ki[i * 4 + 0] * fx + Ki[i * 4 + 1] * fy + Ki[i * 4 + 2]; X[i] = dep * cam[i]; }
-            float p[3];
-            for (int i = 0; i < 3; ++i) p[i] = Pm[i * 4 + 0] * X[0] + Pm[i * 4 + 1] * X[1] + Pm[i * 4 + 2] * X[2] + Pm[i * 4 + 3];
-            const float den = p[2] + 1e-7f;
-            const float u = p[0] / den, v = p[1] / den;
+            backproject_px(Ki, fx, fy, dep, cam, X);
+            float u, v, den;
+            project_px(Pm, X, u, v, den);      // bit for bit the forward's position (geometry_dev.h)
             const Sample s = sample_coords(u, v, H, W);
             const float wx1 = s.ix - (float)s.x0, wy1 = s.iy - (float)s.y0;
             const float wx0 = (float)(s.x0 + 1) - s.ix, wy0 = (float)(s.y0 + 1) - s.iy;
@@ -667,7 +665,7 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(Pyramid pyr, const unsign
         const float dep = disp_to_depth_dev(disp, da, db, dmode);
         const float fx = (float)x, fy = (float)y;
         float cam[3], X[3];
-        for (int i = 0; i < 3; ++i) { cam[i] = Ki[i * 4 + 0] * fx + Ki[i * 4 + 1] * fy + Ki[i * 4 + 2]; X[i] = dep * cam[i]; }
+        backproject_px(Ki, fx, fy, dep, cam, X);
         float ddepth = 0.f;
 #pragma unroll 1
         for (int fi = 0; fi < 2; ++fi) {   // not unrolled: halves the live registers (occupancy 2 -> 4 waves/SIMD)
@@ -676,10 +674,8 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(Pyramid pyr, const unsign
             photo_grad_px(sl, coef + (size_t)n * 9 * HW, warped + (size_t)n * 3 * HW, target + (size_t)b * 3 * HW, H, W, y, x,
                           (unsigned char)(2 + fi), g3);
             const float* Pm = P + (size_t)n * 12;
-            float p[3];
-            for (int i = 0; i < 3; ++i) p[i] = Pm[i * 4 + 0] * X[0] + Pm[i * 4 + 1] * X[1] + Pm[i * 4 + 2] * X[2] + Pm[i * 4 + 3];
-            const float den = p[2] + 1e-7f;
-            const float u = p[0] / den, v = p[1] / den;
+            float u, v, den;
+            project_px(Pm, X, u, v, den);
             const Sample s = sample_coords(u, v, H, W);
             const float wx1 = s.ix - (float)s.x0, wy1 = s.iy - (float)s.y0;
             const float wx0 = (float)(s.x0 + 1) - s.ix, wy0 = (float)(s.y0 + 1) - s.iy;

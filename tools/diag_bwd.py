@@ -111,11 +111,19 @@ def run_depth():
     outs['depth', sc].retain_grad()
     for f in (-1, 1):
         outs['rgb', f, sc].retain_grad()
-    l['loss'].backward()
-    return o, outs
+    l['loss'].backward(retain_graph=True)
+    full = outs['depth', sc].grad.clone()      # (retain_grad's hook would add the partial passes below to .grad)
+    wgrads = {f: outs['rgb', f, sc].grad.clone() for f in (-1, 1)}
+    parts = {}
+    for f in (-1, 1):       # dL/d depth through ONE source frame's synthesised image only
+        parts[f] = torch.autograd.grad(outs['rgb', f, sc], outs['depth', sc], grad_outputs=wgrads[f], retain_graph=True)[0][:, 0]
+    outs['depth', sc].grad = full
+    for f in (-1, 1):
+        outs['rgb', f, sc].grad = wgrads[f]
+    return o, outs, parts
 
 
-o, outs = run_depth()
+o, outs, parts = run_depth()
 ex = outs['depth', sc].grad[:, 0]
 e = (mine - ex).abs()
 bw = int(e.reshape(B, -1).max(1).values.argmax())
@@ -135,3 +143,96 @@ for fi, f in enumerate((-1, 1)):
 print('  depth', float(dep[bw, y, x]), 'disp_up', float(d_up[bw, y, x]))
 nb = e[bw, max(0, y - 2):y + 3, max(0, x - 2):x + 3]
 print('  |err| 5x5 neighbourhood / rms:', (nb / ex[bw].pow(2).mean().sqrt()).numpy().round(3).tolist())
+print('  exact dL/d depth there through frame -1 only:', float(parts[-1][bw, y, x]), ' through frame +1 only:', float(parts[1][bw, y, x]),
+      ' sum', float(parts[-1][bw, y, x] + parts[1][bw, y, x]))
+# the same split for every pixel: where does the kernel path equal ONE part instead of the sum?
+only_m1 = ((mine - parts[-1]).abs() < 1e-3 * ex.abs().clamp_min(1e-12)) & (parts[1].abs() > 1e-2 * ex.abs().clamp_min(1e-12))
+only_p1 = ((mine - parts[1]).abs() < 1e-3 * ex.abs().clamp_min(1e-12)) & (parts[-1].abs() > 1e-2 * ex.abs().clamp_min(1e-12))
+bad = (mine - ex).abs() > 0.05 * ex.abs().clamp_min(1e-3 * float(ex.abs().max()))
+print(f'  pixels off by > 5 %: {int(bad.sum())}; of all pixels, kernel value == frame -1 part only: {int(only_m1.sum())}, == frame +1 part only: {int(only_p1.sum())}')
+ys, xs = torch.nonzero(bad.any(0), as_tuple=True)
+print('  rows of the bad pixels mod 8:', sorted(set((ys % 8).tolist())), ' list:', [(int(b_), int(y_), int(x_)) for b_, y_, x_ in torch.nonzero(bad)[:12]])
+
+# ---- the SSIM derivative coefficients the forward stored for the selected frame (ws.coef, planes c*3+j = alpha/beta/gamma of
+# channel c) against a float64 recomputation from the kernel path's OWN synthesised images: d(0.85/3 * clamp((1-S)/2))/dx_p of
+# pixel q's SSIM w.r.t. any pixel p of its 3x3 patch = alpha_c + beta_c x_p + gamma_c y_p
+import torch.nn.functional as F
+coefs = ws.coef[sc].cpu().double()                       # (B, 9, H, W)
+selc = sel[sc].long()
+tgt = batch['rgb', 0, 0].double()
+ref = torch.zeros_like(coefs)
+C1, C2 = 0.01 ** 2, 0.03 ** 2
+for fi, f in enumerate((-1, 1)):
+    xw = out['rgb', f, sc].detach().cpu().double()
+    xp, yp = F.pad(xw, (1, 1, 1, 1), mode='reflect'), F.pad(tgt, (1, 1, 1, 1), mode='reflect')
+    mu_x, mu_y = F.avg_pool2d(xp, 3, 1), F.avg_pool2d(yp, 3, 1)
+    sx, sy = F.avg_pool2d(xp * xp, 3, 1) - mu_x ** 2, F.avg_pool2d(yp * yp, 3, 1) - mu_y ** 2
+    sxy = F.avg_pool2d(xp * yp, 3, 1) - mu_x * mu_y
+    n1, n2 = 2 * mu_x * mu_y + C1, 2 * sxy + C2
+    d1, d2 = mu_x ** 2 + mu_y ** 2 + C1, sx + sy + C2
+    S = n1 * n2 / (d1 * d2)
+    raw = (1 - S) / 2
+    kf = torch.where((raw >= 0) & (raw <= 1), torch.full_like(raw, (0.85 / 3) * (-0.5) / 9), torch.zeros_like(raw)) / (d1 * d2)
+    al, be, ga = kf * (2 * mu_y * (n2 - n1) - S * 2 * mu_x * (d2 - d1)), kf * (-2 * S * d1), kf * (2 * n1)
+    mine_f = torch.stack([al[:, 0], be[:, 0], ga[:, 0], al[:, 1], be[:, 1], ga[:, 1], al[:, 2], be[:, 2], ga[:, 2]], 1)
+    m = (selc == 2 + fi).unsqueeze(1)
+    ref = torch.where(m, mine_f, ref)
+used = (selc >= 2).unsqueeze(1).expand_as(coefs)
+err = ((coefs - ref).abs() * used)
+scale = ref.abs().amax(1, keepdim=True).clamp_min(1e-9)
+relc = (err / scale).amax(1)
+print(f'stored SSIM coefficients vs float64 recomputation (scale {sc}): worst relative error {float(relc.max()):.2e}; pixels above 1e-2: {int((relc > 1e-2).sum())}, '
+      f'above 1e-3: {int((relc > 1e-3).sum())} of {int((selc >= 2).sum())}')
+for b_, y_, x_ in torch.nonzero(relc > 1e-2)[:8]:
+    print(f'   sample {int(b_)} pixel ({int(y_)},{int(x_)}) sel {int(selc[b_, y_, x_])}: stored {coefs[b_, :3, y_, x_].tolist()} float64 {ref[b_, :3, y_, x_].tolist()}')
+
+# ---- at the worst pixel: dL/d(synthesised image) rebuilt in float64 from the STORED coefficients (what the backward kernel
+# combines: sum over the 3x3 neighbours q that selected the frame of alpha_q + beta_q x_p + gamma_q y_p, + the L1 sign if p itself did)
+wq = (1.0 / B) / (H * W) / 4.0
+for fi, f in enumerate((-1, 1)):
+    xw = out['rgb', f, sc].detach().cpu().double()[bw, :, y, x]
+    yv = tgt[bw, :, y, x]
+    g = torch.zeros(3, dtype=torch.float64)
+    for dy in (-1, 0, 1):
+        for dx in (-1, 0, 1):
+            qy, qx = y + dy, x + dx
+            if not (0 <= qy < H and 0 <= qx < W) or int(selc[bw, qy, qx]) != 2 + fi:
+                continue
+            wgt = (2.0 if (qy == 0 and y == 1) or (qy == H - 1 and y == H - 2) else 1.0) * (2.0 if (qx == 0 and x == 1) or (qx == W - 1 and x == W - 2) else 1.0)
+            cq = coefs[bw, :, qy, qx].reshape(3, 3)          # [channel][alpha, beta, gamma]
+            g += wgt * (cq[:, 0] + cq[:, 1] * xw + cq[:, 2] * yv)
+    if int(selc[bw, y, x]) == 2 + fi:
+        g += (0.15 / 3) * torch.sign(xw - yv)
+    print(f'  frame {f}: dL/d warped from the stored coefficients {(g * wq).tolist()}   exact {outs["rgb", f, sc].grad[bw, :, y, x].tolist()}')
+
+# ---- the geometric part at the worst pixel in float64 from the kernel path's own inputs (projection matrices, inverse
+# intrinsics, depth, source image): does the FORMULA give the oracle's number or the kernel's?
+Pall = ws.P.cpu().double()                                  # (2, B, 3, 4)
+Kinv = ws.ctx.Kinv.cpu().double()[bw]
+dpx = float(dep[bw, y, x])
+cam = Kinv[:3, :3] @ torch.tensor([float(x), float(y), 1.0], dtype=torch.float64)
+tot = 0.0
+for fi, f in enumerate((-1, 1)):
+    Pm = Pall[fi, bw]
+    pvec = Pm[:, :3] @ (dpx * cam) + Pm[:, 3]
+    den = pvec[2] + 1e-7
+    u, v = pvec[0] / den, pvec[1] / den
+    ix, iy = min(max(float(u), 0.0), W - 1.0), min(max(float(v), 0.0), H - 1.0)
+    mx, my = float(0.0 < u < W - 1), float(0.0 < v < H - 1)
+    c = cells[sc, fi, bw, y, x].item()
+    cx0, cy0 = c & 0xFFF, (c >> 12) & 0xFFF
+    src = batch['rgb', f, 0][bw].double()
+    x1, y1 = min(cx0 + 1, W - 1), min(cy0 + 1, H - 1)
+    x1ok, y1ok = float(cx0 + 1 <= W - 1), float(cy0 + 1 <= H - 1)
+    wx1, wy1 = ix - cx0, iy - cy0
+    wx0, wy0 = 1 - wx1, 1 - wy1
+    g = outs['rgb', f, sc].grad[bw, :, y, x]
+    nw, ne, sw, se = src[:, cy0, cx0], src[:, cy0, x1] * x1ok, src[:, y1, cx0] * y1ok, src[:, y1, x1] * x1ok * y1ok
+    gix = float((g * (-nw * wy0 + ne * wy0 - sw * wy1 + se * wy1)).sum()) * mx
+    giy = float((g * (-nw * wx0 - ne * wx1 + sw * wx0 + se * wx1)).sum()) * my
+    a = Pm[:, :3] @ cam
+    dd = (gix * (a[0] * (Pm[2, 3] + 1e-7) - a[2] * Pm[0, 3]) + giy * (a[1] * (Pm[2, 3] + 1e-7) - a[2] * Pm[1, 3])) / den ** 2
+    tot += float(dd)
+    print(f'  frame {f}: float64 formula: u {float(u):.5f} v {float(v):.5f} den {float(den):.6f} cell ({cx0},{cy0}) floor ({int(ix)},{int(iy)}) '
+          f'unclipped x/y {mx:.0f}/{my:.0f} (kernel flags {(c >> 24) & 1}/{(c >> 25) & 1}) du {gix:.4e} dv {giy:.4e} -> dL/d depth {float(dd):.6e}')
+print(f'  float64 formula total {tot:.6e}   kernel path {float(mine[bw, y, x]):.6e}   oracle {float(ex[bw, y, x]):.6e}')

@@ -1,6 +1,8 @@
-"""Diagnostic (GPU): are the bilinear-cell decisions of the forward (warp_fwd order) and of the loss backward's expression
-order the same?  And: a finite check of the backward -- the warped image re-sampled at the readout cells equals the
-forward's warped image bit for bit (i.e. the readout IS the forward's decision)."""
+"""Diagnostic (GPU): is the read-out of the bilinear cells (clslam_warp_cells_pyramid) the decision the forward took?  Every
+synthesised pixel must lie in the hull of the four taps of its read-out cell.  (The sampling position is computed by ONE
+contraction-free function chain shared by the forward, the loss backward and the read-out -- geometry_dev.h -- so the three
+agree to the bit by construction; before round 3's fix the backward could floor a sample within one ulp of a cell boundary
+to the neighbouring cell.)"""
 import os, sys
 from pathlib import Path
 ROOT = Path(__file__).resolve().parents[1]
@@ -17,13 +19,9 @@ noise = synth.make_noise(B, H, W, seed=15)
 p.set_tie_break_noise(noise)
 out, losses = p.adapt(None, {k: v.clone() for k, v in batch.items()}, steps=1)
 ws = p.engine._ws[B]
-cells = []
-for v in ('0', '1'):
-    os.environ['CLSLAM_CELLS_VARIANT'] = v
-    c = torch.empty(4, 2, B, H, W, dtype=torch.int32, device='cuda')
-    ops.warp_cells_pyramid(ws.disp, ws.ctx.Kinv, ws.P, c, p.min_depth, p.max_depth)
-    cells.append(c.cpu())
-print('variant 0 vs 1 mismatches:', int((cells[0] != cells[1]).sum()), 'of', cells[0].numel())
+c = torch.empty(4, 2, B, H, W, dtype=torch.int32, device='cuda')
+ops.warp_cells_pyramid(ws.disp, ws.ctx.Kinv, ws.P, c, p.min_depth, p.max_depth)
+cells = [c.cpu()]
 # forward consistency: nearest-corner reconstruction of warped from the cells is not possible without the weights; instead
 # check that the warped value lies within the convex hull of the four taps of the readout cell (violations = readout != forward)
 c = cells[0].long()

@@ -12,6 +12,17 @@ export TMPDIR=/tmp
 # its timings with counter files of another build)
 python -c "import sys; sys.path.insert(0, 'cl-slam_amd'); from clslam_hip import _lib; print(_lib.build_id())" 2>/dev/null | tail -1 > $OUT/${TAG}_build_id.txt
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/${TAG}_smoke.txt 2>&1
+# counter passes FIRST: bench.py below then finds a counter file of ITS build and reports roofline.traffic from it
+for ctr in FETCH_SIZE WRITE_SIZE; do
+    rm -rf /tmp/pmc_$ctr
+    (cd /tmp && CLSLAM_SIDE_STREAM=0 rocprofv3 --pmc $ctr -d /tmp/pmc_$ctr -o run -- python $OLDPWD/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-also > /tmp/pmc_$ctr.log 2>&1)
+    db=$(ls /tmp/pmc_$ctr/*/*.db /tmp/pmc_$ctr/*.db 2>/dev/null | head -1)
+    python tools/pmc_summary.py $db conv > $OUT/${TAG}_pmc_$ctr.txt 2>&1
+    eval "DB_$ctr=$db"
+done
+# L2-miss traffic per launch of every conv kernel, keyed by kernel name: bench.py's roofline.traffic reads THIS file
+python tools/pmc_traffic.py $DB_FETCH_SIZE $DB_WRITE_SIZE $OUT/${TAG}_pmc_traffic.json > $OUT/${TAG}_pmc_traffic.log 2>&1
+cp $OUT/${TAG}_pmc_traffic.json profiles/pmc_traffic.json
 python bench.py --dump-convs > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 grep "^# conv" $OUT/${TAG}_bench.err > $OUT/${TAG}_conv_launches.txt
 prof() {   # name, env..., then bench args after --
@@ -24,15 +35,6 @@ prof() {   # name, env..., then bench args after --
 }
 prof 3streams CLSLAM_SIDE_STREAM=1
 prof serial CLSLAM_SIDE_STREAM=0
-for ctr in FETCH_SIZE WRITE_SIZE; do
-    rm -rf /tmp/pmc_$ctr
-    (cd /tmp && CLSLAM_SIDE_STREAM=0 rocprofv3 --pmc $ctr -d /tmp/pmc_$ctr -o run -- python $OLDPWD/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-also > /tmp/pmc_$ctr.log 2>&1)
-    db=$(ls /tmp/pmc_$ctr/*/*.db /tmp/pmc_$ctr/*.db 2>/dev/null | head -1)
-    python tools/pmc_summary.py $db conv > $OUT/${TAG}_pmc_$ctr.txt 2>&1
-    eval "DB_$ctr=$db"
-done
-# L2-miss traffic per launch of every conv kernel, keyed by kernel name: bench.py's roofline.traffic reads THIS file
-python tools/pmc_traffic.py $DB_FETCH_SIZE $DB_WRITE_SIZE $OUT/${TAG}_pmc_traffic.json > $OUT/${TAG}_pmc_traffic.log 2>&1
 brief() { python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print({k: d.get(k) for k in ('value', 'unit', 'ms_per_step', 'also')}, d['config']['workload'][:70])"; }
 {
   for r in 0 2 32; do echo "== 192x640 replay $r"; python bench.py --replay $r --steps 20 --warmup 5 --no-cpu-baseline | brief; done
