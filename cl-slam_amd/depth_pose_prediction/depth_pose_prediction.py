@@ -553,8 +553,10 @@ class DepthPosePrediction:
         """Move the caller's dict to the device in place like dpp.py:916-917, asynchronously: the copies run on their own
         stream (pinned sources: DataLoader(pin_memory=True), slam.py:86), the three network inputs first, then the ten
         other entries the path reads, then everything else (upload_all_inputs=False: left on the host).  Returns the
-        events (rgb_aug[0] there, rgb_aug[-1] there, rgb_aug[+1] there, everything the path reads there, the whole dict
-        there) for the engine's streams / the caller's stream to wait on, or None when nothing had to move."""
+        events (rgb_aug[0] there, rgb_aug[-1] there, rgb_aug[+1] there, everything the path reads there) for the engine's
+        streams to wait on plus the list of entries the path does NOT read -- _upload_rest() moves those once the forward
+        has been enqueued, so that their ~0.15 ms of host-side copy calls sit behind GPU work instead of in front of it --
+        or None when nothing had to move."""
         dev = self.device
         todo = [k for k in self.UPLOAD_FIRST + self.UPLOAD_REST if k in inputs and inputs[k].device != dev]
         known = set(self.UPLOAD_FIRST + self.UPLOAD_REST)
@@ -593,13 +595,23 @@ class DepthPosePrediction:
                     copy(k)
             all_ev = torch.cuda.Event()
             all_ev.record(cs)
-            dict_ev = all_ev
-            if extra:                        # not read by the step: only the caller's stream is ordered behind them
-                for k in extra:
-                    copy(k, (cur,))          # never read by the engine: only the caller's stream may touch them
-                dict_ev = torch.cuda.Event()
-                dict_ev.record(cs)
-        return evs[0], evs[1], evs[2], all_ev, dict_ev
+        return evs[0], evs[1], evs[2], all_ev, extra
+
+    def _upload_rest(self, inputs: Dict[Any, Tensor], extra) -> None:
+        """The entries of the caller's dict the path never reads (dpp.py:916-917 moves them too): enqueued on the copy stream
+        after the forward's launches; the caller's stream is ordered behind them, nothing of the step waits for them."""
+        if not extra:
+            return
+        dev = self.device
+        cur = torch.cuda.current_stream(dev)
+        with torch.cuda.stream(self._copy_stream):
+            for k in extra:
+                t = inputs[k].to(dev, non_blocking=True)
+                t.record_stream(cur)         # never read by the engine: only the caller's stream may touch it
+                inputs[k] = t
+            ev = torch.cuda.Event()
+            ev.record(self._copy_stream)
+        cur.wait_event(ev)      # the dict is device-resident from the caller's stream's point of view when the call returns
 
     def _process_batch(self, inputs: Dict[Any, Tensor], loss_sample_weights: Optional[Tensor] = None,
                        use_online: bool = False, train: bool = False, graphed: bool = False, copy_inputs: bool = True,
@@ -618,9 +630,8 @@ class DepthPosePrediction:
         else:
             outputs, losses = self.engine.forward(inputs, train=train, sample_w=sample_w, smooth_w=smooth_w,
                                                   noise=self._injected_noise, reuse_frozen=reuse_frozen, inputs_ready=ready)
-        if ready is not None and ready[4] is not ready[3]:
-            # the caller's dict is device-resident from its stream's point of view when the call returns (dpp.py:916-917)
-            torch.cuda.current_stream(self.device).wait_event(ready[4])
+        if ready is not None:
+            self._upload_rest(inputs, ready[4])
         if self._dp is not None and train:
             # only training steps are collective: predict() / adapt(online, None) on one rank (slam.py:178 on the
             # rank that holds the online frame) must not pair up with another rank's gradient exchange

@@ -363,3 +363,33 @@ def test_descriptor_pass_is_memoised_for_the_single_triplet_forward(backend):
     assert runs[True][1] == (1, 3, 3, 3) and runs[False][1] == (0, 0, 0, 0)
     for a, b in zip(runs[True][0], runs[False][0]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+def test_images_that_need_a_conversion_wait_for_the_whole_upload():
+    """non-fp32 / non-contiguous images are converted by a torch kernel on the MAIN stream; with the asynchronous
+    upload that kernel used to be ordered behind the first image's copy only and could read planes still crossing PCIe.
+    A pinned float64 host minibatch (exactly the fp32 values) and a channels-last one must give bitwise the fp32 result,
+    repeatedly (fresh device blocks every call)."""
+    use_backend('hip')
+    B = 3
+    batch = synth.make_batch(B, 192, 640, seed=77)
+    noise = {s: v.cuda() for s, v in synth.make_noise(B, 192, 640, seed=78).items()}
+    ref = None
+    for kind in ('fp32', 'fp64', 'channels_last'):
+        p = make_predictor(192, 640, B)
+        p.set_tie_break_noise(noise)
+        for rep in range(3):
+            feed = {}
+            for k, v in batch.items():
+                if k[0] in ('rgb', 'rgb_aug') and kind == 'fp64':
+                    v = v.double()
+                elif k[0] in ('rgb', 'rgb_aug') and kind == 'channels_last':
+                    v = v.contiguous(memory_format=torch.channels_last)
+                feed[k] = v.clone(memory_format=torch.preserve_format).pin_memory()
+            out, losses = p.adapt(dict(feed), None)
+            got = (out['depth', 0].clone(), out['cam_T_cam', 0, 1].clone(), losses['loss'].clone())
+            if ref is None:
+                ref = got
+            for a, b in zip(ref, got):
+                assert torch.equal(a, b), (kind, rep)
