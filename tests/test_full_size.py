@@ -93,7 +93,9 @@ def test_b5_step_is_the_sum_of_its_shards_and_deterministic(capsys):
     mx = float(diff.abs().max() / g_full.abs().max())
     with capsys.disabled():
         print(f'[hip 192x640 B=5] shard-sum rule (3 + 2): relative L2 {l2:.2e}, max {mx:.2e}')
-    assert l2 < 2e-2 and mx < 5e-2, (l2, mx)
+    # measured on the MI355X over the round's builds: L2 3.7e-3 ... 5.2e-3, max 4.8e-3 ... 5.6e-3 (a handful of kink flips between
+    # the B = 5 and the 3 + 2 forwards, tests/test_backward_parity.py counts them)
+    assert l2 < 1.2e-2 and mx < 1.5e-2, (l2, mx)
     for k in ('loss', 'velocity_loss', 'reprojection_loss/scale_0', 'smooth_loss/scale_0', 'reg_loss/scale_3'):
         assert abs(float(l_a[k]) + float(l_b[k]) - float(l_full[k])) < 2e-5 * max(abs(float(l_full[k])), 1e-4), k
 
