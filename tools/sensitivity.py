@@ -12,6 +12,7 @@ from clslam_hip import ops, synth
 import depth_pose_prediction.depth_pose_prediction as dpp
 
 H, W, B = 192, 640, int(sys.argv[1]) if len(sys.argv) > 1 else 5
+S = int(sys.argv[2]) if len(sys.argv) > 2 else 1      # optimizer steps per adapt() call (5: the reference's shipped setting)
 dpp.DepthPosePrediction._raise_on_nan = lambda self, *a, **k: None
 p = bench.build_predictor(H, W, B)
 batch = {k: v.cuda() for k, v in synth.make_batch(B, H, W, seed=0).items()}
@@ -20,11 +21,11 @@ orig = {n: getattr(ops, n) for n in dir(ops) if callable(getattr(ops, n)) and no
 
 def timed(n=40, warm=12):
     for _ in range(warm):
-        p.adapt(None, batch, steps=1)
+        p.adapt(None, batch, steps=S)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(n):
-        p.adapt(None, batch, steps=1)
+        p.adapt(None, batch, steps=S)
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / n * 1e3
 
