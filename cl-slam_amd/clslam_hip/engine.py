@@ -383,7 +383,7 @@ class Engine:
         ws.coef = E(4, B, 9, H, W)       # SSIM coefficients of the selected frame per pixel
         t.ddisp_up = E(4, B, H, W)
         t.nb2 = ops.loss_bwd2_blocks(H, W)
-        t.dp_partial = E(4, B, t.nb2, 24)
+        t.dp_partial = torch.empty(4, B, t.nb2, 24, dtype=torch.float64, device=dev)   # block sums of dL/dP, in double
         t.dz_disp = [torch.empty(B, H >> s, W >> s, device=dev) for s in range(4)]
         t.dpose = E(2 * B, 12)
         t.dz = {k: torch.empty_like(v) for k, v in ws.x.items()}   # d(pre-ELU) of every upconv output

@@ -359,12 +359,12 @@ def warp_bwd(dpred, disp_s, src_m1, src_p1, inv_k, proj, ddisp_up, dp_partial, m
     B, H, W = ddisp_up.shape[0], ddisp_up.shape[-2], ddisp_up.shape[-1]
     h, w = disp_s.shape[-2:]
     _lib.get_lib().call('clslam_warp_bwd', _p(dpred), _p(disp_s), h, w, _p(src_m1), _p(src_p1), _p(inv_k), _p(proj),
-                        _p(ddisp_up), _p(dp_partial), B, H, W, _nd(min_depth), _nd(max_depth), _stream(dpred))
+                        _p(ddisp_up), _pa(dp_partial, torch.float64), B, H, W, _nd(min_depth), _nd(max_depth), _stream(dpred))
 
 
 def pose_bwd(dp_partial, nscale, nblk, pose, kmat, dist0, dist1, sample_w, vel_scale, dpose):
     B = kmat.shape[0]
-    _lib.get_lib().call('clslam_pose_bwd', _p(dp_partial), nscale, nblk, _p(pose), _p(kmat), _pa(dist0, torch.float64),
+    _lib.get_lib().call('clslam_pose_bwd', _pa(dp_partial, torch.float64), nscale, nblk, _p(pose), _p(kmat), _pa(dist0, torch.float64),
                         _pa(dist1, torch.float64), _p(sample_w), float(vel_scale or 0.0), _p(dpose), B, _stream(pose))
 
 
@@ -498,7 +498,7 @@ def loss_bwd_pyramid(disps, sel, coef, warped, target, src_m1, src_p1, inv_k, pr
                      min_depth, max_depth):
     B, H, W = ddisp_up.shape[1], ddisp_up.shape[-2], ddisp_up.shape[-1]
     _lib.get_lib().call('clslam_loss_bwd_pyramid', _ptr4(disps), _pa(sel, torch.uint8), _p(coef), _p(warped), _p(target),
-                        _p(src_m1), _p(src_p1), _p(inv_k), _p(proj), _p(sample_w), _p(ddisp_up), _p(dp_partial), B, H, W,
+                        _p(src_m1), _p(src_p1), _p(inv_k), _p(proj), _p(sample_w), _p(ddisp_up), _pa(dp_partial, torch.float64), B, H, W,
                         _nd(min_depth), _nd(max_depth), _stream(ddisp_up))
 
 
@@ -551,5 +551,5 @@ def loss_bwd2_pyramid(disps, sel, coef_sel, warped, target, src_m1, src_p1, inv_
                       min_depth, max_depth):
     B, H, W = ddisp_up.shape[1], ddisp_up.shape[-2], ddisp_up.shape[-1]
     _lib.get_lib().call('clslam_loss_bwd2_pyramid', _ptr4(disps), _pa(sel, torch.uint8), _p(coef_sel), _p(warped), _p(target),
-                        _p(src_m1), _p(src_p1), _p(inv_k), _p(proj), _p(sample_w), _p(ddisp_up), _p(dp_partial), B, H, W,
+                        _p(src_m1), _p(src_p1), _p(inv_k), _p(proj), _p(sample_w), _p(ddisp_up), _pa(dp_partial, torch.float64), B, H, W,
                         _nd(min_depth), _nd(max_depth), _stream(ddisp_up))

@@ -126,15 +126,15 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(const float* __restrict__
                                                        int h, int w, const float* __restrict__ src_m1,
                                                        const float* __restrict__ src_p1, const float* __restrict__ Kinv,
                                                        const float* __restrict__ P, float* __restrict__ ddisp_up,
-                                                       float* __restrict__ dP_partial, int B, int H, int W, float da, float db,
+                                                       double* __restrict__ dP_partial, int B, int H, int W, float da, float db,
                                                        int dmode, int pix_per_block) {
-    __shared__ float red[4][24];
+    __shared__ double red[4][24];
     const int b = blockIdx.y;
     const int HW = H * W;
     const int p0 = blockIdx.x * pix_per_block, p1 = min(HW, p0 + pix_per_block);
-    float dPacc[24];
+    double dPacc[24];       // (stand-alone form for the kernel-level tests: accumulators in double from the first term)
 #pragma unroll
-    for (int k = 0; k < 24; ++k) dPacc[k] = 0.f;
+    for (int k = 0; k < 24; ++k) dPacc[k] = 0.0;
     const float* Ki = Kinv + (size_t)b * 16;
     for (int pi = p0 + (int)threadIdx.x; pi < p1; pi += 256) {
         const int x = pi % W, y = pi / W;
@@ -186,77 +186,83 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(const float* __restrict__
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < 24; ++k) {
-        const float s = wave_sum(dPacc[k]);
+        const double s = wave_sum_f64(dPacc[k]);
         if (lane == 0) red[wave][k] = s;
     }
     __syncthreads();
     if (threadIdx.x < 24)
         dP_partial[((size_t)b * gridDim.x + blockIdx.x) * 24 + threadIdx.x] =
-            red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+            (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
 // ------------------------------------------------------------------------------------------------
-// One block per sample b.  Phase 1: dP[fi][12] = sum over (scale, block) partials (42 row-lanes x 6
-// float4 columns, fixed order).  Phase 2 (threads 0,1 = frame idx): the pose chain backward (autograd of
+// One block per sample b.  Phase 1: dP[fi][12] = sum over (scale, block) partials (40 row-lanes x 6 column
+// quads, fixed order).  Phase 2 (threads 0,1 = frame idx): the pose chain backward (autograd of
 // utils.py:34-117 and layers.py:94) plus the velocity-loss gradient (dpp.py:1125-1146).
-__global__ __launch_bounds__(256) void pose_bwd_kernel(const float* __restrict__ dP_partial, int nscale, int nblk,
+// EVERYTHING HERE IS DOUBLE: the partials arrive as doubles (wave_sum_f64 in the loss backward), and dM = K^T dP below
+// subtracts products of |K| ~ 300-600 whose sum is orders of magnitude smaller (dP[2] is -(u dP[0] + v dP[1]) pixel by
+// pixel, u ~ cx) -- in fp32 this one spot put the pose-decoder gradients of the B = 5 benchmark step 4.5x further from
+// the float64 gradient than torch's own fp32 autograd (7.4e-4 vs 1.6e-4, profiles/r03_backward_parity.txt).  24 numbers
+// per sample: the precision is free.
+__global__ __launch_bounds__(256) void pose_bwd_kernel(const double* __restrict__ dP_partial, int nscale, int nblk,
                                                        const float* __restrict__ pose, const float* __restrict__ Kmat,
                                                        const double* __restrict__ dist0, const double* __restrict__ dist1,
                                                        const float* __restrict__ sample_w, float vel_scale,
                                                        float* __restrict__ dpose, int B) {
-    constexpr int RL = 42;                 // row lanes: 42 x 6 float4 columns = 252 threads
-    __shared__ float4 red[RL][6];
-    __shared__ float dPs[24];
+    constexpr int RL = 40;                 // row lanes: 40 x 6 quads of doubles = 240 threads
+    __shared__ double red[RL][24];
+    __shared__ double dPs[24];
     const int b = blockIdx.x;
     {
-        // 16-byte loads, 42 independent row lanes (a 10-lane scalar version was a ~25 us chain of dependent-
+        // 32-byte rows of four doubles, 40 independent row lanes (a 10-lane scalar version was a ~25 us chain of dependent-
         // latency loads: 960 partial rows per sample at 192x640)
         const int q = threadIdx.x % 6, rl = threadIdx.x / 6;
         if (rl < RL) {
-            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
             for (int sc = 0; sc < nscale; ++sc) {
-                const float4* base = reinterpret_cast<const float4*>(dP_partial + ((size_t)sc * B + b) * nblk * 24) + q;
+                const double* base = dP_partial + ((size_t)sc * B + b) * nblk * 24 + 4 * q;
                 for (int blk = rl; blk < nblk; blk += RL) {
-                    const float4 v = base[(size_t)blk * 6];
-                    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+                    const double* r = base + (size_t)blk * 24;      // (the compiler merges the four into two 16-byte loads)
+                    s0 += r[0]; s1 += r[1]; s2 += r[2]; s3 += r[3];
                 }
             }
-            red[rl][q] = s;
+            red[rl][q * 4 + 0] = s0; red[rl][q * 4 + 1] = s1; red[rl][q * 4 + 2] = s2; red[rl][q * 4 + 3] = s3;
         }
     }
     __syncthreads();
     if (threadIdx.x < 24) {
-        float s = 0.f;
-        for (int r = 0; r < RL; ++r) s += reinterpret_cast<const float*>(&red[r][0])[threadIdx.x];
+        double s = 0.0;
+        for (int r = 0; r < RL; ++r) s += red[r][threadIdx.x];
         dPs[threadIdx.x] = s;
     }
     __syncthreads();
     if (threadIdx.x >= 2) return;
     const int fi = threadIdx.x;
     const int n = fi * B + b;
-    float dP[12];
+    double dP[12];
     for (int k = 0; k < 12; ++k) dP[k] = dPs[fi * 12 + k];
     const float* K = Kmat + (size_t)b * 16;
     // dM[k][j] = sum_{i<3} K[i][k] * dP[i][j]
-    float dM[4][4];
+    double dM[4][4];
     for (int k = 0; k < 4; ++k)
-        for (int j = 0; j < 4; ++j) dM[k][j] = K[0 * 4 + k] * dP[0 * 4 + j] + K[1 * 4 + k] * dP[1 * 4 + j] + K[2 * 4 + k] * dP[2 * 4 + j];
+        for (int j = 0; j < 4; ++j)
+            dM[k][j] = (double)K[0 * 4 + k] * dP[0 * 4 + j] + (double)K[1 * 4 + k] * dP[1 * 4 + j] + (double)K[2 * 4 + k] * dP[2 * 4 + j];
     const float* ps = pose + (size_t)n * 12;
-    const float vx = ps[0], vy = ps[1], vz = ps[2];
-    const float t[3] = {ps[3], ps[4], ps[5]};
-    const float angle = sqrtf(vx * vx + vy * vy + vz * vz);
-    const float inv = angle + 1e-7f;
-    const float x = vx / inv, y = vy / inv, z = vz / inv;
-    const float ca = cosf(angle), sa = sinf(angle), C = 1.f - ca;
-    const float R[3][3] = {{x * x * C + ca, x * y * C - z * sa, z * x * C + y * sa},
-                           {x * y * C + z * sa, y * y * C + ca, y * z * C - x * sa},
-                           {z * x * C - y * sa, y * z * C + x * sa, z * z * C + ca}};
-    float G[3][3], dt[3];
+    const double vx = ps[0], vy = ps[1], vz = ps[2];
+    const double t[3] = {(double)ps[3], (double)ps[4], (double)ps[5]};
+    const double angle = sqrt(vx * vx + vy * vy + vz * vz);
+    const double inv = angle + 1e-7;
+    const double x = vx / inv, y = vy / inv, z = vz / inv;
+    const double ca = cos(angle), sa = sin(angle), C = 1.0 - ca;
+    const double R[3][3] = {{x * x * C + ca, x * y * C - z * sa, z * x * C + y * sa},
+                            {x * y * C + z * sa, y * y * C + ca, y * z * C - x * sa},
+                            {z * x * C - y * sa, y * z * C + x * sa, z * z * C + ca}};
+    double G[3][3], dt[3];
     if (fi == 0) {  // inverted: M3 = R^T, Mt[i] = -sum_k R[k][i] t[k]
         for (int i = 0; i < 3; ++i)
             for (int j = 0; j < 3; ++j) G[i][j] = dM[j][i];
         for (int k = 0; k < 3; ++k) {
-            float s = 0.f;
+            double s = 0.0;
             for (int i = 0; i < 3; ++i) {
                 G[k][i] += -t[k] * dM[i][3];
                 s += R[k][i] * dM[i][3];
@@ -269,32 +275,32 @@ __global__ __launch_bounds__(256) void pose_bwd_kernel(const float* __restrict__
             dt[i] = dM[i][3];
         }
     }
-    const float xC = x * C, yC = y * C, zC = z * C;
-    const float s01 = G[0][1] + G[1][0], s02 = G[0][2] + G[2][0], s12 = G[1][2] + G[2][1];
-    float dx = G[0][0] * 2.f * xC + s01 * yC + s02 * zC + (G[2][1] - G[1][2]) * sa;
-    float dy = G[1][1] * 2.f * yC + s01 * xC + s12 * zC + (G[0][2] - G[2][0]) * sa;
-    float dz = G[2][2] * 2.f * zC + s02 * xC + s12 * yC + (G[1][0] - G[0][1]) * sa;
-    const float dC = G[0][0] * x * x + G[1][1] * y * y + G[2][2] * z * z + s01 * x * y + s02 * z * x + s12 * y * z;
-    const float dca = G[0][0] + G[1][1] + G[2][2] - dC;
-    const float dsa = (G[1][0] - G[0][1]) * z + (G[0][2] - G[2][0]) * y + (G[2][1] - G[1][2]) * x;
-    float dtheta = -sa * dca + ca * dsa;
+    const double xC = x * C, yC = y * C, zC = z * C;
+    const double s01 = G[0][1] + G[1][0], s02 = G[0][2] + G[2][0], s12 = G[1][2] + G[2][1];
+    const double dx = G[0][0] * 2.0 * xC + s01 * yC + s02 * zC + (G[2][1] - G[1][2]) * sa;
+    const double dy = G[1][1] * 2.0 * yC + s01 * xC + s12 * zC + (G[0][2] - G[2][0]) * sa;
+    const double dz = G[2][2] * 2.0 * zC + s02 * xC + s12 * yC + (G[1][0] - G[0][1]) * sa;
+    const double dC = G[0][0] * x * x + G[1][1] * y * y + G[2][2] * z * z + s01 * x * y + s02 * z * x + s12 * y * z;
+    const double dca = G[0][0] + G[1][1] + G[2][2] - dC;
+    const double dsa = (G[1][0] - G[0][1]) * z + (G[0][2] - G[2][0]) * y + (G[2][1] - G[1][2]) * x;
+    double dtheta = -sa * dca + ca * dsa;
     dtheta += -(dx * vx + dy * vy + dz * vz) / (inv * inv);
-    float dv[3] = {dx / inv, dy / inv, dz / inv};
-    if (angle > 0.f) { dv[0] += dtheta * vx / angle; dv[1] += dtheta * vy / angle; dv[2] += dtheta * vz / angle; }
+    double dv[3] = {dx / inv, dy / inv, dz / inv};
+    if (angle > 0.0) { dv[0] += dtheta * vx / angle; dv[1] += dtheta * vy / angle; dv[2] += dtheta * vz / angle; }
     // velocity loss: frame idx 0 (translation 0->-1) pairs with relative_distance(0), idx 1 with (1)
     if (vel_scale > 0.f) {
         const double gt = fabs(fi == 0 ? dist0[b] : dist1[b]);
-        const float nrm = sqrtf(t[0] * t[0] + t[1] * t[1] + t[2] * t[2]);
+        const float nrm = sqrtf(ps[3] * ps[3] + ps[4] * ps[4] + ps[5] * ps[5]);
         const double diff = (double)nrm - gt;
-        const float sg = diff > 0.0 ? 1.f : (diff < 0.0 ? -1.f : 0.f);
+        const double sg = diff > 0.0 ? 1.0 : (diff < 0.0 ? -1.0 : 0.0);
         if (nrm > 0.f) {
-            const float coef = sample_w[b] * vel_scale * 0.5f * sg / nrm;
+            const double coef = (double)sample_w[b] * (double)vel_scale * 0.5 * sg / (double)nrm;
             dt[0] += coef * t[0]; dt[1] += coef * t[1]; dt[2] += coef * t[2];
         }
     }
     float* o = dpose + (size_t)n * 12;
-    o[0] = dv[0]; o[1] = dv[1]; o[2] = dv[2];
-    o[3] = dt[0]; o[4] = dt[1]; o[5] = dt[2];
+    o[0] = (float)dv[0]; o[1] = (float)dv[1]; o[2] = (float)dv[2];
+    o[3] = (float)dt[0]; o[4] = (float)dt[1]; o[5] = (float)dt[2];
     for (int k = 6; k < 12; ++k) o[k] = 0.f;
 }
 
@@ -400,7 +406,7 @@ extern "C" int clslam_warp_cells_pyramid(const float* const* disp, const float* 
 extern "C" int clslam_warp_bwd_blocks(int H, int W) { return std::max(1, std::min(256, cdiv(H * W, 1024))); }
 
 extern "C" int clslam_warp_bwd(const float* dpred, const float* disp_s, int h, int w, const float* src_m1,
-                               const float* src_p1, const float* inv_k, const float* proj, float* ddisp_up, float* dp_partial,
+                               const float* src_p1, const float* inv_k, const float* proj, float* ddisp_up, double* dp_partial,
                                int batch, int H, int W, float min_depth, float max_depth, void* stream) {
     CLSLAM_REQUIRE(dpred && disp_s && src_m1 && src_p1 && inv_k && proj && ddisp_up && dp_partial, "warp_bwd: null");
     float a, b; int mode;
@@ -413,7 +419,7 @@ extern "C" int clslam_warp_bwd(const float* dpred, const float* disp_s, int h, i
     return check_launch("warp_bwd");
 }
 
-extern "C" int clslam_pose_bwd(const float* dp_partial, int nscale, int nblk, const float* pose, const float* kmat,
+extern "C" int clslam_pose_bwd(const double* dp_partial, int nscale, int nblk, const float* pose, const float* kmat,
                                const double* dist0, const double* dist1, const float* sample_w, float vel_scale,
                                float* dpose, int batch, void* stream) {
     CLSLAM_REQUIRE(dp_partial && pose && kmat && dpose && sample_w, "pose_bwd: null");

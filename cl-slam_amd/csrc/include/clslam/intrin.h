@@ -51,6 +51,30 @@ __device__ __forceinline__ float wave_sum(float v) {
            (__builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 48)));
 }
 
+// The same in double: the 24 pose-gradient sums of the loss backward (a few million terms of both signs per sample, and
+// K^T dP cancels |u| ~ 600 against them afterwards) are reduced in double from the wave level on -- 24 numbers per block,
+// free.  Each 64-bit value travels as two DPP moves.
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov_f64(double v) {
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), CTRL, 0xF, 0xF, false);
+    return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo);
+}
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, lane);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), lane);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | (unsigned long long)lo);
+}
+__device__ __forceinline__ double wave_sum_f64(double v) {
+    v += dpp_mov_f64<0xB1>(v);
+    v += dpp_mov_f64<0x4E>(v);
+    v += dpp_mov_f64<0x141>(v);
+    v += dpp_mov_f64<0x140>(v);
+    return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
+}
+
 // Cross-workgroup hand-off inside one kernel (split-K gather).  MI355X has one L2 per XCD and they are
 // not coherent with each other for ordinary accesses; a device-scope __threadfence() makes them so by
 // writing back / invalidating the whole L2 (measured: ~300 us per conv when 1280 workgroups do it).

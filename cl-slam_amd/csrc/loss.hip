@@ -204,14 +204,14 @@ __global__ __launch_bounds__(256) void loss_bwd2_kernel(Pyramid pyr, const unsig
                                                         const float* __restrict__ target, const float* __restrict__ src_m1,
                                                         const float* __restrict__ src_p1, const float* __restrict__ Kinv,
                                                         const float* __restrict__ P, const float* __restrict__ sample_w,
-                                                        float* __restrict__ ddisp_up_all, float* __restrict__ dP_partial, int B,
+                                                        float* __restrict__ ddisp_up_all, double* __restrict__ dP_partial, int B,
                                                         int H, int W, float da, float db, int dmode, int tilesX) {
     // coefficients pixel-major, 10 floats per pixel as five pairs (alpha_0 alpha_1)(alpha_2 beta_0)(beta_1 beta_2)
     // (gamma_0 gamma_1)(gamma_2 -): a neighbour is five ds_read_b64 + five v_pk_fma instead of nine reads + nine FMAs
     // (40-byte stride: conflict-free for 8-byte reads)
     __shared__ f32x2 cs[LB_PH * LB_PW][5];
     __shared__ unsigned char ss[LB_PH * LB_PW];
-    __shared__ float red[4][24];
+    __shared__ double red[4][24];     // the pose-gradient sums leave the thread in double (wave_sum_f64)
     const int b = blockIdx.y, sc = blockIdx.z;
     const int HW = H * W;
     const int ty = blockIdx.x / tilesX, tx = blockIdx.x - ty * tilesX;
@@ -340,14 +340,14 @@ __global__ __launch_bounds__(256) void loss_bwd2_kernel(Pyramid pyr, const unsig
         }
 #pragma unroll
         for (int k = 0; k < 12; ++k) {
-            const float s = wave_sum(dPacc[k]);
+            const double s = wave_sum_f64((double)dPacc[k]);     // a thread holds two pixels' terms; from here on: double
             if (lane == 0) red[wave][fi * 12 + k] = s;
         }
     }
     __syncthreads();
     if (threadIdx.x < 24)
         dP_partial[(((size_t)sc * B + b) * gridDim.x + blockIdx.x) * 24 + threadIdx.x] =
-            red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+            (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -642,9 +642,9 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(Pyramid pyr, const unsign
                                                        const float* __restrict__ target, const float* __restrict__ src_m1,
                                                        const float* __restrict__ src_p1, const float* __restrict__ Kinv,
                                                        const float* __restrict__ P, const float* __restrict__ sample_w,
-                                                       float* __restrict__ ddisp_up_all, float* __restrict__ dP_partial, int B,
+                                                       float* __restrict__ ddisp_up_all, double* __restrict__ dP_partial, int B,
                                                        int H, int W, float da, float db, int dmode, int pix_per_block) {
-    __shared__ float red[4][24];
+    __shared__ double red[4][24];
     const int b = blockIdx.y, sc = blockIdx.z;
     const int HW = H * W;
     const int h = pyr.h[sc], w = pyr.w[sc];
@@ -655,9 +655,9 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(Pyramid pyr, const unsign
     float* ddisp_up = ddisp_up_all + (size_t)sc * B * HW;
     const float wq = sample_w[b] / ((float)H * (float)W) / 4.f;
     const int p0 = blockIdx.x * pix_per_block, p1 = min(HW, p0 + pix_per_block);
-    float dPacc[24];
+    double dPacc[24];
 #pragma unroll
-    for (int k = 0; k < 24; ++k) dPacc[k] = 0.f;
+    for (int k = 0; k < 24; ++k) dPacc[k] = 0.0;
     const float* Ki = Kinv + (size_t)b * 16;
     for (int pi = p0 + (int)threadIdx.x; pi < p1; pi += 256) {
         const int x = pi % W, y = pi / W;
@@ -718,13 +718,13 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(Pyramid pyr, const unsign
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < 24; ++k) {
-        const float s = wave_sum(dPacc[k]);
+        const double s = wave_sum_f64(dPacc[k]);
         if (lane == 0) red[wave][k] = s;
     }
     __syncthreads();
     if (threadIdx.x < 24)
         dP_partial[(((size_t)sc * B + b) * gridDim.x + blockIdx.x) * 24 + threadIdx.x] =
-            red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+            (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -967,7 +967,7 @@ extern "C" int clslam_loss_bwd2_blocks(int H, int W) { return cdiv(H, LB_TH) * c
 extern "C" int clslam_loss_bwd2_pyramid(const float* const* disp, const unsigned char* sel, const float* coef_sel,
                                         const float* warped, const float* target, const float* src_m1, const float* src_p1,
                                         const float* inv_k, const float* proj, const float* sample_w, float* ddisp_up,
-                                        float* dp_partial, int batch, int H, int W, float min_depth, float max_depth, void* stream) {
+                                        double* dp_partial, int batch, int H, int W, float min_depth, float max_depth, void* stream) {
     CLSLAM_REQUIRE(disp && sel && coef_sel && warped && target && src_m1 && src_p1 && inv_k && proj && sample_w && ddisp_up &&
                    dp_partial, "loss_bwd2_pyramid: null");
     float a, b; int mode;
@@ -986,7 +986,7 @@ extern "C" int clslam_loss_bwd_blocks(int H, int W) { return std::max(1, std::mi
 // coef (4,2,B,9,H,W), warped (4,2,B,3,H,W); ddisp_up (4,B,H,W); dp_partial [4][B][nblk][24].
 extern "C" int clslam_loss_bwd_pyramid(const float* const* disp, const unsigned char* sel, const float* coef, const float* warped,
                                        const float* target, const float* src_m1, const float* src_p1, const float* inv_k,
-                                       const float* proj, const float* sample_w, float* ddisp_up, float* dp_partial, int batch,
+                                       const float* proj, const float* sample_w, float* ddisp_up, double* dp_partial, int batch,
                                        int H, int W, float min_depth, float max_depth, void* stream) {
     CLSLAM_REQUIRE(disp && sel && coef && warped && target && src_m1 && src_p1 && inv_k && proj && sample_w && ddisp_up &&
                    dp_partial, "loss_bwd_pyramid: null");

@@ -197,11 +197,11 @@ int clslam_warp_cells_pyramid(const float* const* disp, const float* inv_k, cons
 int clslam_warp_bwd_blocks(int H, int W);
 /* ddisp_up (B,H,W) = dL/d(upsampled disparity); dp_partial [B][nblk][24] block sums of dL/dproj */
 int clslam_warp_bwd(const float* dpred, const float* disp_s, int h, int w, const float* src_m1, const float* src_p1,
-                    const float* inv_k, const float* proj, float* ddisp_up, float* dp_partial, int batch, int H, int W,
+                    const float* inv_k, const float* proj, float* ddisp_up, double* dp_partial, int batch, int H, int W,
                     float min_depth, float max_depth, void* stream);
 /* dp_partial [nscale][B][nblk][24]; dpose (2B,12) = dL/d(pose-decoder output) incl. the velocity
  * term (dpp.py:1125-1146; dist0/dist1 = relative_distance(0|1) as float64, sample_w (B)).        */
-int clslam_pose_bwd(const float* dp_partial, int nscale, int nblk, const float* pose, const float* kmat,
+int clslam_pose_bwd(const double* dp_partial, int nscale, int nblk, const float* pose, const float* kmat,
                     const double* dist0, const double* dist1, const float* sample_w, float vel_scale, float* dpose,
                     int batch, void* stream);
 
@@ -253,14 +253,14 @@ int clslam_smooth_intended_bwd(const float* const* disp, const float* const* rgb
 int clslam_loss_bwd2_blocks(int H, int W);
 int clslam_loss_bwd2_pyramid(const float* const* disp, const unsigned char* sel, const float* coef_sel, const float* warped,
                              const float* target, const float* src_m1, const float* src_p1, const float* inv_k,
-                             const float* proj, const float* sample_w, float* ddisp_up, float* dp_partial, int batch,
+                             const float* proj, const float* sample_w, float* ddisp_up, double* dp_partial, int batch,
                              int H, int W, float min_depth, float max_depth, void* stream);
 /* Fused clslam_photo_grad + clslam_warp_bwd for all four scales: sel (4,B,H,W), coef (4,2,B,9,H,W),
  * warped (4,2,B,3,H,W) -> ddisp_up (4,B,H,W), dp_partial [4][B][clslam_loss_bwd_blocks][24].          */
 int clslam_loss_bwd_blocks(int H, int W);
 int clslam_loss_bwd_pyramid(const float* const* disp, const unsigned char* sel, const float* coef, const float* warped,
                             const float* target, const float* src_m1, const float* src_p1, const float* inv_k,
-                            const float* proj, const float* sample_w, float* ddisp_up, float* dp_partial, int batch, int H,
+                            const float* proj, const float* sample_w, float* ddisp_up, double* dp_partial, int batch, int H,
                             int W, float min_depth, float max_depth, void* stream);
 int clslam_disp_grad_pyramid(const float* ddisp_up, const float* const* disp, const float* smooth_aux, int n_smooth,
                              float* const* dz, int batch, int H, int W, void* stream);

@@ -60,6 +60,17 @@ inline float wave_sum(float v) {
     return v;
 }
 
+inline double wave_sum_f64(double v) {
+    const int l = lane_id();
+    for (int off = 32; off >= 1; off >>= 1) {
+        double* s = reinterpret_cast<double*>(emu_wave_scratch() + emu_wave_phase() * 128);
+        s[l] = v;
+        emu_sync_wave();
+        v = v + s[l ^ off];
+    }
+    return v;
+}
+
 inline float fast_rcp(float x) { return 1.f / x; }
 
 // blocks run on several host threads: real atomics / fences

@@ -61,7 +61,7 @@ def _run_loss_stage(dev, inputs, disp, pose, noise, sample_w, smooth_w, H, W, mi
     dz = []
     if pyramid:
         nb2 = ops.loss_bwd2_blocks(H, W)
-        dp_partial = torch.empty(4, B, nb2, 24, device=dev)
+        dp_partial = torch.empty(4, B, nb2, 24, dtype=torch.float64, device=dev)
         ddisp_all = torch.empty(4, B, H, W, device=dev)
         ops.loss_bwd2_pyramid(disp_d, sel, coef_sel, warped, src[0], src[-1], src[1], Kinv, P, t(sample_w), ddisp_all, dp_partial,
                               min_depth, max_depth)
@@ -69,7 +69,7 @@ def _run_loss_stage(dev, inputs, disp, pose, noise, sample_w, smooth_w, H, W, mi
         ops.disp_grad_pyramid(ddisp_all, disp_d, aux if n_smooth else None, n_smooth, dz, H, W)
     else:
         nb2 = ops.warp_bwd_blocks(H, W)
-        dp_partial = torch.empty(4, B, nb2, 24, device=dev)
+        dp_partial = torch.empty(4, B, nb2, 24, dtype=torch.float64, device=dev)
         dpred = torch.empty(2, B, 3, H, W, device=dev)
         ddisp_up = torch.empty(B, H, W, device=dev)
         for s in range(4):
