@@ -8,7 +8,8 @@ One "step" = one `DepthPosePrediction.adapt(online, training, steps=1)`: forward
 view synthesis + loss, hand-written backward, fused Adam -- on a synthetic minibatch of 1 online
 triplet + R replayed triplets that is already resident in HBM when the timed region starts (bench contract), followed by
 what slam/slam.py:181-188 does with the result every frame: the online sample's pose and every loss scalar read back to
-the host (`--no-readback` leaves that out).  The PCIe-inclusive frame of SURVEY.md 8(d) (pinned host minibatch -> H2D
+the host (`--no-readback` leaves that out), on the product's DEFAULT boundary -- outputs and losses are device tensors
+exactly like the reference's (`--host-outputs` times the opt-in host-output path instead).  The PCIe-inclusive frame of SURVEY.md 8(d) (pinned host minibatch -> H2D
 inside adapt()) is measured by the same run and reported under `also.end_to_end`; by the contract it is never `value`.
 N = 1 runs BASELINE config 3 (R = 4, B = 5, the configuration the 30 frames/s target is quoted on);
 `--replay R` selects another replay count (R = 0 is BASELINE config 2).
@@ -41,7 +42,7 @@ import torch  # noqa: E402
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4_f32
 
 
-def build_predictor(H, W, B_cfg, host_outputs=True):
+def build_predictor(H, W, B_cfg, host_outputs=False):
     from types import SimpleNamespace
     from clslam_hip import synth
     from depth_pose_prediction import Config, DepthPosePrediction
@@ -122,9 +123,13 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-readback', action='store_true', help='do not read the pose and the loss scalars back to the host inside '
                     'the timed region of `value` (slam.py:181-188 does, every frame)')
-    ap.add_argument('--device-outputs', action='store_true', help='reference-default boundary: adapt() returns pose and losses as '
-                    'device tensors (the readback then waits for the backward + optimizer step); default here is the '
-                    'product\'s opt-in host-output fast path (host_pose_output=True)')
+    ap.add_argument('--host-outputs', action='store_true', help='time the product\'s OPT-IN host-output path (host_pose_output=True: '
+                    'pose + losses handed out as host tensors staged behind the forward) instead of the default boundary '
+                    '(device tensors like the reference; the training step runs detached on the engine\'s stream)')
+    ap.add_argument('--device-outputs', action='store_true', help='(default since round 4; kept for old command lines)')
+    ap.add_argument('--lcd', action='store_true', help='BASELINE config 5: the loop-closure encoder forward on rgb(+1, 0) of the online '
+                    'frame inside every timed frame (slam.py:223 -> loop_closure_detection.py:41-51); closed-form weights, '
+                    'parity of that encoder is UNPINNED (DESIGN.md)')
     ap.add_argument('--no-also', action='store_true', help='skip the extra adapt(steps=5) timing (profiling runs)')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo lets two '
                     'ranks share one GPU for a functional check of the sharded path)')
@@ -161,7 +166,7 @@ def main():
     from clslam_hip import _lib, ops, synth
     build_id = _lib.build_id()
     torch.manual_seed(1 + rank)          # the tie-break noise is drawn on the device: same trajectory every run
-    p = build_predictor(H, W, B if N == 1 else Bl, host_outputs=not args.device_outputs)
+    p = build_predictor(H, W, B if N == 1 else Bl, host_outputs=args.host_outputs)
     if N > 1:
         p.enable_data_parallel(B, offset)
     full = synth.make_batch(B, H, W, seed=0)
@@ -185,10 +190,19 @@ def main():
         vals = {k: float(v.squeeze().cpu().detach().numpy()) for k, v in losses.items()}
         return T, vals
 
+    lcd_enc = None
+    if args.lcd and rank == 0:
+        from clslam_hip import lcd as lcd_mod
+        from loop_closure_detection import FeatureEncoder
+        lcd_enc = FeatureEncoder(dev, weights=lcd_mod.synthetic_state_dict())
+        lcd_image = batch['rgb', 1, 0][0]
+
     def step():
         out = p.adapt(None, batch, steps=S)
         if not args.no_readback:
             consume(*out)
+        if lcd_enc is not None:      # slam.py:223: after the pose has been read back, on the rank that holds the online frame
+            lcd_enc(lcd_image)
         return out
 
     def sync():
@@ -218,40 +232,46 @@ def main():
 
         def frame():
             out = p.adapt(None, dict(host), steps=S)     # a fresh dict per frame: adapt() moves its entries in place
-            return consume(*out)
-        for _ in range(3):
+            r = consume(*out)
+            if lcd_enc is not None:
+                lcd_enc(host['rgb', 1, 0][0])
+            return r
+
+        def timed(groups_n):
             frame()
-        groups = []
-        for _ in range(3):
-            sync()
-            t0 = time.perf_counter()
-            for _ in range(10):
-                frame()
-            sync()
-            groups.append((time.perf_counter() - t0) / 10 * 1e3)
-        ms_e2e = sorted(groups)[1]
-        # the same frame with the reference's default boundary (pose + losses as device tensors: the first .cpu() waits for
-        # the backward + optimizer step, then one small D2H per loss key)
-        prev = p.host_pose_output
-        p.host_pose_output = False
-        frame()
-        ref_groups = []
+            groups = []
+            for _ in range(groups_n):
+                sync()
+                t0 = time.perf_counter()
+                for _ in range(10):
+                    frame()
+                sync()
+                groups.append((time.perf_counter() - t0) / 10 * 1e3)
+            return sorted(groups)[len(groups) // 2]
         for _ in range(2):
-            sync()
-            t0 = time.perf_counter()
-            for _ in range(10):
-                frame()
-            sync()
-            ref_groups.append((time.perf_counter() - t0) / 10 * 1e3)
+            frame()
+        ms_e2e = timed(3)
+        # the same frame on the other boundary (opt-in host outputs <-> reference-default device outputs)
+        prev = p.host_pose_output
+        p.host_pose_output = not prev
+        ms_other = timed(3)
         p.host_pose_output = prev
+        # ... and with the training step on the caller's stream (rounds 1-3: the first .cpu() waits for backward + Adam)
+        p.engine.detached_training = False
+        ms_attached = timed(3)
+        p.engine.detached_training = True
         up = [k for k in host if isinstance(host[k], torch.Tensor)] if p.upload_all_inputs else [k for k in p.UPLOAD_FIRST + p.UPLOAD_REST if k in host]
+        ms_dev, ms_host = (ms_other, ms_e2e) if prev else (ms_e2e, ms_other)
         e2e = {'ms_per_frame': round(ms_e2e, 3), 'frames_per_s': round(1e3 / ms_e2e, 2),
+               'boundary': 'opt-in host outputs' if prev else 'reference default (device outputs)',
                'h2d_mbytes_per_frame': round(sum(host[k].numel() * host[k].element_size() for k in up) / 1e6, 2),
                'h2d_tensors': len(up), 'of_tensors_in_sample_dict': len(host),
-               'ms_per_frame_with_device_outputs': round(min(ref_groups), 3),
+               'ms_per_frame_with_device_outputs': round(ms_dev, 3),
+               'ms_per_frame_with_host_outputs': round(ms_host, 3),
+               'ms_per_frame_step_on_callers_stream': round(ms_attached, 3),
                'includes': 'H2D of the whole sample dict from pinned host memory (dpp.py:916-917; copy stream, network inputs '
                            'first, entries the path never reads last), adapt(), cam_T_cam[0] and the loss scalars on the host '
-                           '(slam.py:181-188)'}
+                           '(slam.py:181-188)' + (', loop-closure encoder forward (slam.py:223)' if lcd_enc is not None else '')}
 
     also = None
     if N == 1 and S == 1 and not args.no_also:
@@ -350,9 +370,11 @@ def main():
                        'parallelism': f'dp{N}' if N > 1 else 'single', 'shards': counts,
                        'timed_region': 'minibatch resident in HBM -> adapt() -> ' + ('nothing read back' if args.no_readback else
                                        'cam_T_cam[0] and every loss scalar on the host (slam.py:181-188)'),
-                       'boundary': 'reference default: outputs and losses are device tensors' if args.device_outputs else
-                                   'opt-in host-output fast path (host_pose_output=True): pose + losses handed out as host tensors '
-                                   'staged behind the forward',
+                       'boundary': 'opt-in host-output path (host_pose_output=True): pose + losses handed out as host tensors '
+                                   'staged behind the forward' if args.host_outputs else
+                                   'reference default: outputs and losses are device tensors; the training step runs detached on '
+                                   'the engine stream (the read-back waits for the forward + 3 launches)',
+                       'lcd_encoder_in_frame': bool(args.lcd),
                        'loss': float(losses['loss'])},
             'build_id': build_id,
             'roofline': roof, 'cpu_baseline': cpu,

@@ -101,7 +101,7 @@ def _device_streams(device) -> Dict[str, Any]:
     key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
     pool = _STREAM_POOL.get(key)
     if pool is None:
-        pool = {name: torch.cuda.Stream(device=device) for name in ('side', 'wg', 'capture', 'tail')}
+        pool = {name: torch.cuda.Stream(device=device) for name in ('main', 'side', 'wg', 'tail', 'capture')}
         _STREAM_POOL[key] = pool
     return pool
 
@@ -127,12 +127,14 @@ class Engine:
         self.vel_scale = float(velocity_loss_scaling) if velocity_loss_scaling else 0.0
         self.layout = TrainableLayout()
         n = self.layout.size
-        self.w = torch.zeros(n, device=device)
+        # the four arenas; `engine.w / g / m / v` (properties below) are the same tensors for OUTSIDE readers: the access
+        # orders the current stream behind the training step still in flight on the engine's own stream
+        self._w = torch.zeros(n, device=device)
         self._wb_cache: Dict[str, Any] = {}
         self._main = None
-        self.g = torch.zeros(n, device=device)
-        self.m = torch.zeros(n, device=device)
-        self.v = torch.zeros(n, device=device)
+        self._g = torch.zeros(n, device=device)
+        self._m = torch.zeros(n, device=device)
+        self._v = torch.zeros(n, device=device)
         self.adam_step_count = 0
         self.enc: Dict[str, Any] = {}
         self._ws: Dict[int, SimpleNamespace] = {}
@@ -149,12 +151,23 @@ class Engine:
         # queues, and a third predictor's twelfth stream lands on the queue of its own main stream -- 3.84 instead of
         # 3.33 ms per step measured with three predictors alive)
         pool = _device_streams(device)
+        # The engine's own in-order compute stream.  A training adapt() runs there: forward, backward and the optimizer step
+        # are enqueued behind each other, the CALLER's stream is only ordered behind the FORWARD (an event), so what the
+        # reference's callers do next -- outputs['cam_T_cam', 0, 1][0].cpu(), losses[k].cpu() (slam.py:181-188) -- waits for
+        # the forward alone while backward + Adam keep the GPU busy; whatever touches trainable state or the workspace
+        # afterwards is ordered behind the step by wait_training().  CLSLAM_DETACHED_TRAINING=0: everything on the caller's
+        # stream like rounds 1-3 (bitwise the same results, tests/test_detached_training.py).
+        self.main_stream = pool.get('main')
+        self.detached_training = os.environ.get('CLSLAM_DETACHED_TRAINING', '1') != '0'
+        self._train_done = None       # event: the last detached training step (incl. its optimizer step) has completed
+        self._caller = None           # the caller's stream while a detached call is being enqueued
+        self.inputs_released = None
         self.side_stream = pool.get('side')
         self.wg_stream = pool.get('wg')
         # split-K scratch of the small-M 3x3 convs: one zero-filled buffer per stream convs are launched on
         self._conv_ws: Dict[int, torch.Tensor] = pool.setdefault('conv_ws', {}) if pool else {}
         self.capture_stream = pool.get('capture')
-        for st in (self.side_stream, self.wg_stream, self.capture_stream):
+        for st in (self.main_stream, self.side_stream, self.wg_stream, self.capture_stream):
             if st is not None:
                 self._conv_workspace(st.cuda_stream)
         # Asynchronous tail (data-parallel mode): gradient reduction + all-reduce + Adam of step N run on their own
@@ -231,9 +244,58 @@ class Engine:
                 and ops.PROFILE is None)
 
     def wait_training(self, stream=None) -> None:
-        """Make `stream` (default: the current one) wait for the optimizer step in flight on the tail stream."""
+        """Make `stream` (default: the current one) wait for the training step in flight: the optimizer step on the tail
+        stream (data-parallel mode) and / or the detached backward + optimizer step on the engine's own stream."""
         if self._tail_event is not None:
             (stream or torch.cuda.current_stream(self.device)).wait_event(self._tail_event)
+        if self._train_done is not None:
+            (stream or torch.cuda.current_stream(self.device)).wait_event(self._train_done)
+
+    # the arenas for outside readers (tests, tools, checkpointing, the asynchronous mode's snapshots): ordered behind the step
+    @property
+    def w(self) -> torch.Tensor:
+        self.wait_training()
+        return self._w
+
+    @property
+    def g(self) -> torch.Tensor:
+        self.wait_training()
+        return self._g
+
+    @property
+    def m(self) -> torch.Tensor:
+        self.wait_training()
+        return self._m
+
+    @property
+    def v(self) -> torch.Tensor:
+        self.wait_training()
+        return self._v
+
+    def detached_ok(self) -> bool:
+        """A training adapt() may run on the engine's own stream (see __init__)."""
+        return (self.detached_training and self.main_stream is not None and self.device.type == 'cuda'
+                and not self._capturing and ops.PROFILE is None)
+
+    def begin_detached(self):
+        """-> (caller's stream, engine stream): the engine stream is ordered behind everything the caller has enqueued (its
+        inputs) and becomes torch's current stream for the enqueueing that follows (`with torch.cuda.stream(em)`)."""
+        cur = torch.cuda.current_stream(self.device)
+        em = self.main_stream
+        if cur.cuda_stream == em.cuda_stream:      # nested / already there
+            return cur, None
+        em.wait_stream(cur)
+        self._caller = cur
+        return cur, em
+
+    def end_detached(self, cur, released, failed: bool = False) -> None:
+        """The caller's stream continues behind `released` (backward(): the last read of the caller's minibatch, ~0.1 ms into
+        the backward); everything that touches trainable state or the workspace waits through wait_training()."""
+        self._caller = None
+        ev = torch.cuda.Event()
+        ev.record(self.main_stream)
+        self._train_done = ev
+        cur.wait_event(ev if (failed or released is None) else released)
 
     def training_stream(self):
         """Context manager: the stream the gradient all-reduce of the step in flight belongs on."""
@@ -275,7 +337,7 @@ class Engine:
             model, key = name.split('/', 1)
             t = torch.nn.Module.state_dict(self.models[model])[key].detach().to(dev, torch.float32)
             flat = TrainableLayout.to_compute(t)
-            self.w[off:off + flat.numel()].copy_(flat)
+            self._w[off:off + flat.numel()].copy_(flat)
         self._packed_version = self._module_version()
         self._modules_stale = False
         for ws in self._ws.values():           # features of the previous encoder weights are void
@@ -292,7 +354,7 @@ class Engine:
         for name, off, shape in self.layout.entries:
             model, key = name.split('/', 1)
             p = torch.nn.Module.state_dict(self.models[model], keep_vars=True)[key]
-            p.data.copy_(TrainableLayout.to_reference(self.w[off:off + math.prod(shape)], shape))
+            p.data.copy_(TrainableLayout.to_reference(self._w[off:off + math.prod(shape)], shape))
         self._modules_stale = False
         self._packed_version = self._module_version()
 
@@ -302,7 +364,7 @@ class Engine:
         broadcast (clslam_hip.async_mode).  Module parameters are re-materialised lazily like after an optimizer step."""
         self.pack_if_needed()
         self.wait_training()
-        self.w.copy_(flat.reshape(-1)[:self.layout.size])
+        self._w.copy_(flat.reshape(-1)[:self.layout.size])
         if adam_step_count is not None:
             self.adam_step_count = int(adam_step_count)
         self._modules_stale = True
@@ -311,7 +373,7 @@ class Engine:
         self.wait_training()
         for n, off, shape in self.layout.entries:
             if n == name:
-                return self.w[off:off + math.prod(shape)]
+                return self._w[off:off + math.prod(shape)]
         raise KeyError(name)
 
     def _slot(self, buf: torch.Tensor, name: str, numel: int) -> torch.Tensor:
@@ -461,8 +523,8 @@ class Engine:
         # views of the flat weight arena (allocated once, packed in place): built once per layer, ~70 lookups per step
         hit = self._wb_cache.get(prefix)
         if hit is None:
-            w = self._slot(self.w, prefix + '.weight', cout * taps * cin).view(cout, taps, cin)
-            b = self._slot(self.w, prefix + '.bias', cout)
+            w = self._slot(self._w, prefix + '.weight', cout * taps * cin).view(cout, taps, cin)
+            b = self._slot(self._w, prefix + '.bias', cout)
             hit = self._wb_cache[prefix] = (w, b)
         return hit
 
@@ -523,6 +585,10 @@ class Engine:
         # the caller's stream, looked up ONCE per call (torch.cuda.current_stream() costs 3 us; it was asked 30x per step)
         self._main = torch.cuda.current_stream(self.device) if self.device.type == 'cuda' else None
         self._conv_workspace(None if self._main is None else self._main.cuda_stream)
+        if self._train_done is not None and self._main.cuda_stream != self.main_stream.cuda_stream:
+            # a forward on the caller's stream (predict(), adapt(online, None)) after a detached training step: the encoders
+            # below overwrite workspace the backward in flight still reads
+            self._main.wait_event(self._train_done)
         if inputs_ready is not None:
             # inputs still crossing PCIe on the caller's copy stream: events (rgb_aug[0], rgb_aug[-1], rgb_aug[+1], everything
             # there).  The depth net only reads rgb_aug[0], the pose net the three rgb_aug frames; the un-augmented
@@ -560,6 +626,11 @@ class Engine:
             ws.disp = [E(B, H >> s, W >> s) for s in range(4)]
             ws.pose, ws.T = E(2 * B, 12), E(2, B, 4, 4)
             ws.depth, ws.warped, ws.losses = E(4, B, H, W), E(4, 2, B, 3, H, W), E(18)
+            if self._caller is not None:
+                # detached training step: these blocks come from the engine stream's pool and are handed to the caller, who
+                # reads them on ITS stream -- the allocator must not recycle them under a read still queued there
+                for t_ in (*ws.disp, ws.pose, ws.T, ws.depth, ws.warped, ws.losses):
+                    t_.record_stream(self._caller)
         def identity_and_noise() -> bool:
             """Identity reprojection maps (dpp.py:1047-1052) and the tie-break noise depend on the inputs only."""
             if not reuse:
@@ -703,6 +774,11 @@ class Engine:
         if (m is None or not self.descriptor_memo or self._capturing or m.version != self._packed_version
                 or m.x.shape != x.shape or m.x.device != x.device):
             return None
+        # ONE look-up per descriptor pass: slam.py runs the pass (and reads its 512 numbers back, i.e. the stream is drained)
+        # right before the frame's adapt() -- that is the forward that can repeat it.  The comparison reads one byte back,
+        # which is a stream synchronisation: any later forward (another frame without a descriptor pass, the asynchronous
+        # modes) must not pay it against a stale memo while a training step is in flight.
+        self._memo = None
         if not bool(torch.equal(m.x, x)):
             return None
         self.memo_hits += 1
@@ -784,14 +860,14 @@ class Engine:
             splits = ops.wgrad_patch_splits(desc, tb) if use_patch else ops.wgrad_splits(desc, tb)
             plan = SimpleNamespace(use_patch=use_patch, splits=splits, partial=torch.empty(splits * n, device=self.device),
                                    colsum=None, nb=0)
-            t.items.append((plan.partial, self._slot(self.g, name_prefix + '.weight', n), n, splits))
+            t.items.append((plan.partial, self._slot(self._g, name_prefix + '.weight', n), n, splits))
             if bias_blocks:
-                t.items.append((bias_partial, self._slot(self.g, name_prefix + '.bias', cout), cout, bias_blocks))
+                t.items.append((bias_partial, self._slot(self._g, name_prefix + '.bias', cout), cout, bias_blocks))
             else:
                 rows = out_shape[0] * out_shape[1] * out_shape[2]
                 plan.nb = ops.colsum_blocks(rows)
                 plan.colsum = torch.empty(plan.nb * cout, device=self.device)
-                t.items.append((plan.colsum, self._slot(self.g, name_prefix + '.bias', cout), cout, plan.nb))
+                t.items.append((plan.colsum, self._slot(self._g, name_prefix + '.bias', cout), cout, plan.nb))
             t.plan[name_prefix] = plan
         if plan.use_patch:
             ops.conv_wgrad_patch(desc, dz, plan.partial, plan.splits)
@@ -801,9 +877,9 @@ class Engine:
             ops.colsum(dz, plan.colsum, out_shape[0] * out_shape[1] * out_shape[2], cout)
 
     def backward(self, B: int, defer_reduce: bool = False) -> None:
-        """dL/d(trainable arena) for the last training forward; fills self.g (dpp.py:312).
+        """dL/d(trainable arena) for the last training forward; fills self._g (dpp.py:312).
         defer_reduce: the caller promises that adam() follows directly (adapt(), single GPU): the batched reduction of the
-        gradient partials is left to adam(), which fuses it with the update; self.g is complete after THAT launch."""
+        gradient partials is left to adam(), which fuses it with the update; self._g is complete after THAT launch."""
         ws = self._ws[B]
         t = ws.train
         c = ws.ctx
@@ -827,6 +903,13 @@ class Engine:
         if self.smooth_intended:
             ops.smooth_intended_bwd(ws.disp, c.rgb0, ws.si_aux, c.sample_w, t.dz_disp, H, W, self.smooth_scale)
         ops.pose_bwd(t.dp_partial, 4, t.nb2, ws.pose, c.K, c.d0, c.d1, c.sample_w, self.vel_scale, t.dpose)
+        self.inputs_released = None
+        if self._caller is not None:
+            # detached step: nothing below reads the caller's minibatch (frames, intrinsics, distances) or the output planes
+            # handed to it any more -- the three launches above were the last.  The caller's stream continues behind THIS point:
+            # it may overwrite its input buffers in place or drop them at once, like after the reference's synchronous step.
+            self.inputs_released = torch.cuda.Event()
+            self.inputs_released.record(self._main)
         side = self.side_stream if (self.use_side_stream and self.side_stream is not None) else None
         if side is not None:
             main = self._main
@@ -845,7 +928,7 @@ class Engine:
             # (pose_2's gradients are written straight into the arena by pose_head_bwd: identity items, so that every
             # trainable element is the output of exactly one item -- the fused reduction + Adam updates per item)
             for key, n in (('pose_decoder/pose_2.weight', 12 * 256), ('pose_decoder/pose_2.bias', 12)):
-                sl = self._slot(self.g, key, n)
+                sl = self._slot(self._g, key, n)
                 t.items.append((sl, sl, n, 1))
             t.table = ops.make_reduce_table(t.items, self.device)
         self._pending_reduce = None
@@ -856,10 +939,10 @@ class Engine:
             # training_stream()) and Adam follow on the tail stream and nobody waits for them here
             self.tail_stream.wait_stream(self._main)
             with torch.cuda.stream(self.tail_stream):
-                ops.reduce_multi(t.table, len(t.items), self.g)
+                ops.reduce_multi(t.table, len(t.items), self._g)
             self._tail_open = True
         else:
-            ops.reduce_multi(t.table, len(t.items), self.g)
+            ops.reduce_multi(t.table, len(t.items), self._g)
 
     def _transpose_decoder_weights(self, t) -> None:
         """Flipped/transposed weights for every dgrad conv of the step (nine depth-decoder upconvs, pose_0 / pose_1).
@@ -884,7 +967,7 @@ class Engine:
                 wp, _ = self._wb(f'pose_decoder/pose_{k}', 256, 256, 9)
                 items.append((wp, t.wt_pose[k], None))
             t.wt_table = ops.transpose_table(items)
-        ops.weight_transpose_multi(t.wt_table, self.w)
+        ops.weight_transpose_multi(t.wt_table, self._w)
 
     def _backward_depth_decoder(self, ws, t, B: int) -> None:
         """dgrad chain (critical path) on the current stream; every weight/bias gradient is independent
@@ -931,7 +1014,7 @@ class Engine:
                     if i not in t.disp_part:
                         nb = ops.dispconv_wgrad_blocks(B * hi * wi)
                         t.disp_part[i] = torch.empty(nb * (9 * ci + 1), device=self.device)
-                        t.items.append((t.disp_part[i], self._slot(self.g, f'depth_decoder/dispconv_{i}.conv.weight', 9 * ci + 1),
+                        t.items.append((t.disp_part[i], self._slot(self._g, f'depth_decoder/dispconv_{i}.conv.weight', 9 * ci + 1),
                                         9 * ci + 1, nb))
                     ops.dispconv_wgrad(t.dz_disp[i], ws.x[i, 1], t.disp_part[i])
                 on_wg(disp_wgrad)
@@ -973,8 +1056,8 @@ class Engine:
         h5, w5 = H >> 5, W >> 5
         w2_, _ = self._wb('pose_decoder/pose_2', 12, 256, 1)
         ops.pose_head_bwd(t.dpose, ws.p1, w2_.view(12, 256), ws.pmean, t.dz_p1,
-                          self._slot(self.g, 'pose_decoder/pose_2.weight', 12 * 256).view(12, 256),
-                          self._slot(self.g, 'pose_decoder/pose_2.bias', 12))
+                          self._slot(self._g, 'pose_decoder/pose_2.weight', 12 * 256).view(12, 256),
+                          self._slot(self._g, 'pose_decoder/pose_2.bias', 12))
         self._wgrad(t, (ws.p0, None), (n2, h5, w5, 256), t.dz_p1, 'pose_decoder/pose_1', 256, 256, 9)
         # (transposed weights: _transpose_decoder_weights, issued at the start of backward())
         ops.conv2d(t.dz_p1, t.wt_pose[1], t.dz_p0, ksize=3, pad=1, actgrad_src=ws.p0, actgrad_kind=ACT_RELU)
@@ -1096,7 +1179,7 @@ class Engine:
             if guard is not None:
                 guard.record_stream(self.tail_stream)      # a fresh per-call tensor allocated on the caller's stream
             with torch.cuda.stream(self.tail_stream):
-                ops.adam_step(self.w, self.g, self.m, self.v, lr, self.adam_step_count, betas[0], betas[1], eps, guard=guard)
+                ops.adam_step(self._w, self._g, self._m, self._v, lr, self.adam_step_count, betas[0], betas[1], eps, guard=guard)
                 self._tail_event = torch.cuda.Event()
                 self._tail_event.record(self.tail_stream)
             self._tail_open = False
@@ -1105,10 +1188,10 @@ class Engine:
             if self._pending_reduce is not None:
                 table, nitems = self._pending_reduce
                 self._pending_reduce = None
-                ops.reduce_multi_adam(table, nitems, self.g, self.w, self.m, self.v, lr, self.adam_step_count, betas[0], betas[1],
+                ops.reduce_multi_adam(table, nitems, self._g, self._w, self._m, self._v, lr, self.adam_step_count, betas[0], betas[1],
                                       eps, guard=guard)
             else:
-                ops.adam_step(self.w, self.g, self.m, self.v, lr, self.adam_step_count, betas[0], betas[1], eps, guard=guard)
+                ops.adam_step(self._w, self._g, self._m, self._v, lr, self.adam_step_count, betas[0], betas[1], eps, guard=guard)
             self._tail_event = None
         self._modules_stale = True
 
@@ -1118,6 +1201,7 @@ class Engine:
         """NCHW feature list of one encoder, as the reference's ResnetEncoder.forward returns it."""
         self.pack_if_needed()
         self._conv_workspace()
+        self.wait_training()
         x = self._img(x.to(self.device))
         n = x.shape[0]
         nimg = 1 if which == 'depth_encoder' else 2

@@ -44,6 +44,63 @@ def expected_keys() -> List[str]:
     return keys
 
 
+def _make_divisible(v: float, divisor: int = 8) -> int:
+    """torchvision's channel rounding (squeeze channels of the SE blocks = _make_divisible(expanded // 4, 8))."""
+    new_v = max(divisor, int(v + divisor / 2) // divisor * divisor)
+    if new_v < 0.9 * v:
+        new_v += divisor
+    return new_v
+
+
+def state_dict_shapes() -> Dict[str, tuple]:
+    """Key -> shape of the `features.*` part of torchvision's mobilenet_v3_small state dict (what the reference's
+    FeatureEncoder evaluates, loop_closure_detection/encoder.py:22-26)."""
+    shapes: Dict[str, tuple] = {}
+
+    def cba(p, cout, cin_per_group, k):
+        shapes[p + '.0.weight'] = (cout, cin_per_group, k, k)
+        for name in ('weight', 'bias', 'running_mean', 'running_var'):
+            shapes[p + '.1.' + name] = (cout,)
+    cba('features.0', 16, 3, 3)
+    for i, (cin, k, exp, cout, se, act, stride) in enumerate(SETTINGS, start=1):
+        j = 0
+        if exp != cin:
+            cba(f'features.{i}.block.{j}', exp, cin, 1); j += 1
+        cba(f'features.{i}.block.{j}', exp, 1, k); j += 1
+        if se:
+            S = _make_divisible(exp // 4, 8)
+            p = f'features.{i}.block.{j}'
+            shapes[p + '.fc1.weight'], shapes[p + '.fc1.bias'] = (S, exp, 1, 1), (S,)
+            shapes[p + '.fc2.weight'], shapes[p + '.fc2.bias'] = (exp, S, 1, 1), (exp,)
+            j += 1
+        cba(f'features.{i}.block.{j}', cout, exp, 1)
+    cba('features.12', 576, 96, 1)
+    return shapes
+
+
+def synthetic_state_dict(seed: int = 0) -> Dict[str, torch.Tensor]:
+    """Closed-form random-init weights of the architecture (bench.py --lcd and the tests: the ImageNet checkpoint the reference
+    downloads is not available offline).  Same generator as the depth / pose nets' synthetic weights (clslam_hip.synth)."""
+    from . import synth
+    out = {}
+    for k, shape in state_dict_shapes().items():
+        n = 1
+        for d in shape:
+            n *= d
+        u = torch.from_numpy(synth.hash_uniform(max(n, 1), synth._key_seed('lcd/' + k, seed))[:n]).reshape(shape)
+        if len(shape) == 4:
+            out[k] = (u * 2 - 1) * (6.0 / (shape[1] * shape[2] * shape[3])) ** 0.5
+        elif k.endswith('running_var'):
+            out[k] = 0.6 + 0.8 * u
+        elif k.endswith('running_mean'):
+            out[k] = 0.2 * (u - 0.5)
+        elif '.1.weight' in k:
+            out[k] = 0.8 + 0.4 * u
+        else:
+            out[k] = 0.2 * (u - 0.5)
+    return out
+
+
 class MobileNetV3SmallHIP:
     def __init__(self, state_dict: Dict[str, torch.Tensor], device: torch.device) -> None:
         lib = get_lib()

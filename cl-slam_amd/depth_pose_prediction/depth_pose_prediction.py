@@ -65,8 +65,8 @@ class EngineAdam(optim.Adam):
                 off, n = eng.layout.offset[name], math.prod(shape)
                 state[idx] = {
                     'step': torch.tensor(float(eng.adam_step_count)),
-                    'exp_avg': TrainableLayout.to_reference(eng.m[off:off + n], shape).clone(),
-                    'exp_avg_sq': TrainableLayout.to_reference(eng.v[off:off + n], shape).clone(),
+                    'exp_avg': TrainableLayout.to_reference(eng._m[off:off + n], shape).clone(),
+                    'exp_avg_sq': TrainableLayout.to_reference(eng._v[off:off + n], shape).clone(),
                 }
         sd['state'] = state
         return sd
@@ -82,8 +82,8 @@ class EngineAdam(optim.Adam):
         for k in ('lr', 'betas', 'eps'):
             if k in groups[0]:
                 self.param_groups[0][k] = groups[0][k]
-        eng.m.zero_()
-        eng.v.zero_()
+        eng._m.zero_()
+        eng._v.zero_()
         step = 0
         for idx, st in state_dict['state'].items():
             name = self._names[int(idx)]
@@ -92,8 +92,8 @@ class EngineAdam(optim.Adam):
             off = eng.layout.offset[name]
             m = TrainableLayout.to_compute(st['exp_avg'].to(eng.device, torch.float32))
             v = TrainableLayout.to_compute(st['exp_avg_sq'].to(eng.device, torch.float32))
-            eng.m[off:off + m.numel()].copy_(m)
-            eng.v[off:off + v.numel()].copy_(v)
+            eng._m[off:off + m.numel()].copy_(m)
+            eng._v[off:off + v.numel()].copy_(v)
             step = max(step, int(float(st['step'])))
         eng.adam_step_count = step
 
@@ -304,7 +304,7 @@ class DepthPosePrediction:
             bits = t.view(torch.int32).to(torch.int64)
             idx = torch.arange(1, bits.numel() + 1, device=bits.device, dtype=torch.int64)
             return torch.stack([bits.sum(), (bits * (idx % 8191 + 1)).sum()])
-        mine = torch.cat([digest(e.w), digest(e.m), digest(e.v)])
+        mine = torch.cat([digest(e._w), digest(e._m), digest(e._v)])
         lo, hi = mine.clone(), mine.clone()
         dist, group = self._dp['dist'], self._dp['group']
         dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
@@ -343,34 +343,54 @@ class DepthPosePrediction:
         if training_data is not None:
             self._set_adapt(freeze_encoder=True)
             self.engine.pack_if_needed()
-            for it in range(steps):
-                # steps 2..S see the same minibatch through the same frozen, eval-mode encoders (dpp.py:308-313):
-                # their features and the identity-reprojection maps are kept, only the decoders re-run
-                if self.engine.graph_preferred(training_data['rgb_aug', 0, 0].shape[0]):
-                    # forward + backward replayed as one hipGraph (same kernels, same streams)
-                    outputs_eval, losses = self._process_batch(training_data, loss_weights, train=True, graphed=True,
-                                                               copy_inputs=(it == 0), reuse_frozen=(it > 0),
-                                                               want_outputs=(it == steps - 1))
-                    self.optimizer.zero_grad()
-                    self._reduce_gradients()
-                else:
-                    outputs_eval, losses = self._process_batch(training_data, loss_weights, train=True,
-                                                               reuse_frozen=(it > 0))
-                    self.optimizer.zero_grad()
-                    self._backward(training_data)
-                # dpp.py:1115-1118 aborts on a NaN loss before backward/step.  Checking there costs a full host
-                # sync in the middle of the step (the GPU idles while the host enqueues the backward), and a
-                # sync at the end of the step starves the GPU at the start of the next one.  Instead the
-                # forward copies the loss to pinned host memory behind an event; backward and a device-
-                # guarded Adam (no-op when the loss is NaN) are enqueued, and only then does the host wait
-                # for THAT event -- the GPU still has the whole backward queued while the host goes on.
-                self.optimizer.loss_guard = self._losses_dev[17:18]
-                self.optimizer.step()
-                self.optimizer.loss_guard = None
-                losses = self._staged_losses()
-                self._raise_on_nan(losses, undo_step=True)
-                if not self.host_pose_output:        # reference behaviour: the loss dict lives on the device
-                    losses = self.engine.losses_dict(self._losses_dev)
+            # The step runs on the ENGINE's stream (Engine.main_stream): forward, backward and the optimizer step go out
+            # behind each other there, and the caller's stream is only ordered behind the last forward + the first three
+            # launches of its backward (the last reads of the caller's minibatch and of the output planes: ~0.1 ms) -- the
+            # reads the reference's driver does next (slam.py:181-188: cam_T_cam[0].cpu(), one .cpu() per loss key) return
+            # then, while the rest of the backward + Adam keep the GPU busy, and the caller may overwrite or drop its
+            # minibatch at once like after the reference's synchronous step.  Everything that touches trainable state or
+            # the workspace afterwards (the next adapt() / predict() / predict_pose(), state_dict(), save_model(),
+            # engine.w/g/m/v) is ordered behind the step.  CLSLAM_DETACHED_TRAINING=0: the whole step on the caller's stream.
+            eng = self.engine
+            cur = em = released = None
+            if eng.detached_ok():
+                cur, em = eng.begin_detached()
+            failed = True
+            try:
+                with (torch.cuda.stream(em) if em is not None else _null_context()):
+                    for it in range(steps):
+                        # steps 2..S see the same minibatch through the same frozen, eval-mode encoders (dpp.py:308-313):
+                        # their features and the identity-reprojection maps are kept, only the decoders re-run
+                        if eng.graph_preferred(training_data['rgb_aug', 0, 0].shape[0]):
+                            # forward + backward replayed as one hipGraph (same kernels, same streams)
+                            outputs_eval, losses = self._process_batch(training_data, loss_weights, train=True, graphed=True,
+                                                                       copy_inputs=(it == 0), reuse_frozen=(it > 0),
+                                                                       want_outputs=(it == steps - 1))
+                            self.optimizer.zero_grad()
+                            self._reduce_gradients()
+                        else:
+                            outputs_eval, losses = self._process_batch(training_data, loss_weights, train=True,
+                                                                       reuse_frozen=(it > 0))
+                            self.optimizer.zero_grad()
+                            self._backward(training_data)
+                            released = eng.inputs_released if it == steps - 1 else None
+                        # dpp.py:1115-1118 aborts on a NaN loss before backward/step.  Checking there costs a full host
+                        # sync in the middle of the step (the GPU idles while the host enqueues the backward), and a
+                        # sync at the end of the step starves the GPU at the start of the next one.  Instead the
+                        # forward copies the loss to pinned host memory behind an event; backward and a device-
+                        # guarded Adam (no-op when the loss is NaN) are enqueued, and only then does the host wait
+                        # for THAT event -- the GPU still has the whole backward queued while the host goes on.
+                        self.optimizer.loss_guard = self._losses_dev[17:18]
+                        self.optimizer.step()
+                        self.optimizer.loss_guard = None
+                        losses = self._staged_losses()
+                        self._raise_on_nan(losses, undo_step=True)
+                        if not self.host_pose_output:        # reference behaviour: the loss dict lives on the device
+                            losses = self.engine.losses_dict(self._losses_dev)
+                failed = False
+            finally:
+                if em is not None:
+                    eng.end_detached(cur, released, failed=failed)
             if self._pose_staged is not None:
                 # the event _staged_losses() waited for covers the pose copy issued just before the loss copy
                 T = self._pose_host[self._pose_staged].clone()
@@ -576,7 +596,7 @@ class DepthPosePrediction:
         # allocator; record_stream below defers their reuse until the engine's streams are past them), so the copies of
         # frame N+1 need not wait for frame N's backward + optimizer step still queued on the caller's stream -- they cross
         # PCIe underneath it.
-        users = [cur] + [st for st in (self.engine.side_stream, self.engine.wg_stream) if st is not None]
+        users = [cur] + [st for st in (self.engine.side_stream, self.engine.wg_stream, self.engine._caller) if st is not None]
         def copy(k, consumers=users):
             t = inputs[k].to(dev, non_blocking=True)
             for st in consumers:            # consumed on the engine's streams: keep the block until they are past it
@@ -608,6 +628,8 @@ class DepthPosePrediction:
             for k in extra:
                 t = inputs[k].to(dev, non_blocking=True)
                 t.record_stream(cur)         # never read by the engine: only the caller's stream may touch it
+                if self.engine._caller is not None:
+                    t.record_stream(self.engine._caller)
                 inputs[k] = t
             ev = torch.cuda.Event()
             ev.record(self._copy_stream)
@@ -691,7 +713,12 @@ class DepthPosePrediction:
     def _reduce_gradients(self) -> None:
         if self._dp is not None:
             with self.engine.training_stream():     # the tail stream when the engine left the reduction there
-                self._dp['dist'].all_reduce(self.engine.g, group=self._dp['group'])
+                self._dp['dist'].all_reduce(self.engine._g, group=self._dp['group'])
+
+
+def _null_context():
+    import contextlib
+    return contextlib.nullcontext()
 
 
 def _select_device() -> torch.device:

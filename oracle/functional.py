@@ -88,10 +88,15 @@ def backproject(depth: Tensor, inv_K: Tensor) -> Tensor:
     return torch.cat([cam, ones], 1)
 
 
-def project(points: Tensor, K: Tensor, T: Tensor, H: int, W: int, eps: float = 1e-7) -> Tensor:
-    """networks/layers.py:82-104.  -> normalised sampling grid (B,H,W,2)."""
+def project(points: Tensor, K: Tensor, T: Tensor, H: int, W: int, eps: float = 1e-7, P_value: Optional[Tensor] = None) -> Tensor:
+    """networks/layers.py:82-104.  -> normalised sampling grid (B,H,W,2).
+    P_value: test hook -- the VALUE of the projection matrix (K T)[:3] as another implementation rounded it (its fp32
+    product differs from this one's by an ulp per entry, which moves every sample of the frame coherently by ~1e-5 px: a
+    forward-point difference, tests/helpers.py); the gradient path through K T stays."""
     B = points.shape[0]
     P = torch.matmul(K, T)[:, :3, :]
+    if P_value is not None:
+        P = P + (P_value.to(P.dtype) - P).detach()
     cam = torch.matmul(P, points)
     pix = cam[:, :2, :] / (cam[:, 2, :].unsqueeze(1) + eps)
     pix = pix.view(B, 2, H, W).permute(0, 2, 3, 1)
@@ -149,7 +154,7 @@ def grid_sample_border(src: Tensor, grid: Tensor, cells=None, record=None) -> Te
 
 def reconstruct(disp_s: Tensor, T: Dict[int, Tensor], K: Tensor, inv_K: Tensor,
                 src: Dict[int, Tensor], H: int, W: int, min_depth, max_depth,
-                cells=None, record=None) -> Tuple[Tensor, Dict[int, Tensor]]:
+                cells=None, record=None, P_value=None) -> Tuple[Tensor, Dict[int, Tensor]]:
     """dpp.py:986-1017 for one scale: bilinear-upsample disp, disp->depth, backproject,
     project with scale-0 intrinsics, grid_sample the un-augmented scale-0 source frame.
     cells / record: {frame: ...} test hooks of grid_sample_border (the written-out sampler replaces F.grid_sample
@@ -159,7 +164,7 @@ def reconstruct(disp_s: Tensor, T: Dict[int, Tensor], K: Tensor, inv_K: Tensor,
     pts = backproject(depth, inv_K)
     warped = {}
     for f in (-1, 1):
-        grid = project(pts, K, T[f], H, W)
+        grid = project(pts, K, T[f], H, W, P_value=None if P_value is None else P_value.get(f))
         if cells is None and record is None:
             warped[f] = F.grid_sample(src[f], grid, padding_mode='border', align_corners=True)
         else:

@@ -94,7 +94,9 @@ class OraclePredictor:
             depth, warped = OF.reconstruct(outputs[('disp', s)], T, inputs[('camera_matrix', 0)],
                                            inputs[('inv_camera_matrix', 0)], src, H, W,
                                            self.min_depth, self.max_depth,
-                                           cells=None if self.forced_cells is None else self.forced_cells[s], record=rec)
+                                           cells=None if self.forced_cells is None else self.forced_cells[s], record=rec,
+                                           P_value=None if self.forced_forward is None else
+                                           {f: self.forced_forward.get(('P', f)) for f in (-1, 1)})
             if rec is not None:
                 self.last_cells[s] = {f: v[0] for f, v in rec.items()}
             outputs[('depth', s)] = depth
@@ -168,6 +170,28 @@ class OraclePredictor:
             losses['loss'].backward()
             self.optimizer.step()
         return out, losses
+
+    def to_double(self) -> 'OraclePredictor':
+        """The same predictor in float64 (parameters converted in place: the optimizer keeps its references).  Feed it
+        float64 inputs and noise.  This is the yardstick of tests/test_trajectory.py: how far the fp32 restatement itself drifts
+        from exact arithmetic over the reference's shipped `adaptation_epochs: 5` (config/config_adapt.yaml:53, dpp.py:309-313)
+        is the envelope the HIP path is held to."""
+        for m in self.models.values():
+            m.double()
+        return self
+
+    def trajectory(self, training_data: Dict[Any, Tensor], noise_per_step, steps: int):
+        """adapt(steps=steps) (dpp.py:309-319) one optimizer step at a time, recording per step what the later-step parity
+        test compares: the step's forward (pre-update weights: disparity at scale 0, both pose matrices, the loss) and the
+        trainable tensors right after the step's update."""
+        rec = []
+        for it in range(steps):
+            out, losses = self.adapt(training_data, steps=1, noise_per_step=[noise_per_step[it]])
+            w = {f'{model}/{k}': v.detach().clone() for model in ('depth_decoder', 'pose_decoder')
+                 for k, v in self.models[model].state_dict().items()}
+            rec.append({'disp0': out['disp', 0].detach().clone(), 'T-1': out['cam_T_cam', 0, -1].detach().clone(),
+                        'T+1': out['cam_T_cam', 0, 1].detach().clone(), 'loss': float(losses['loss'].detach()), 'w': w})
+        return rec
 
     def predict(self, batch, noise=None):
         self.set_eval()

@@ -72,6 +72,30 @@ def test_predict_matches_reference_golden(backend):
     assert np.array_equal(cov, np.eye(6, dtype=np.float32))
 
 
+def _fp32_envelope(B, steps, batch):
+    """per step: how far the fp32 oracle (= the reference's arithmetic) is from the float64 oracle on the golden case's
+    inputs -- 'out': worst relative distance over the four disparities and both pose matrices of the step's forward,
+    'w_flipped': fraction of trainable weights whose update went the other way (|dw| > lr/2) after the step"""
+    noises = [synth.make_noise(B, H, W, seed=11 + it) for it in range(steps)]
+    b64 = {k: (v.double() if v.is_floating_point() else v) for k, v in batch.items()}
+    o32, o64 = make_oracle(H, W, B), make_oracle(H, W, B).to_double()
+    env = []
+    for it in range(steps):
+        a, _ = o32.adapt(batch, steps=1, noise_per_step=[noises[it]])
+        b, _ = o64.adapt(b64, steps=1, noise_per_step=[{s: v.double() for s, v in noises[it].items()}])
+        keys = [('disp', s) for s in range(4)] + [('cam_T_cam', 0, f) for f in (-1, 1)]
+        out = max(rel_err(a[k].detach(), b[k].detach()) for k in keys)
+        flipped = total = 0
+        for name in ('depth_decoder', 'pose_decoder'):
+            sb = o64.models[name].state_dict()
+            for k, v in o32.models[name].state_dict().items():
+                d = (v.double() - sb[k]).abs().reshape(-1)[:96]      # the golden file's sample: the first 96 entries of each tensor
+                flipped += int((d > 0.5e-4).sum())
+                total += d.numel()
+        env.append({'out': out, 'w_flipped': flipped / total})
+    return env
+
+
 @pytest.mark.parametrize('backend', BACKENDS)
 @pytest.mark.parametrize('case,B,steps', [('adapt_b2', 2, 1), ('adapt_b3', 3, 3)])
 def test_adapt_matches_reference_golden(backend, case, B, steps):
@@ -79,19 +103,22 @@ def test_adapt_matches_reference_golden(backend, case, B, steps):
     g = load_golden(case)
     p = make_predictor(H, W, B)
     batch = synth.make_batch(B, H, W, seed=1 + B)
+    envelope = None
     for it in range(steps):
         p.set_tie_break_noise(synth.make_noise(B, H, W, seed=11 + it))
         outputs, losses = p.adapt(None, {k: v.clone() for k, v in batch.items()}, steps=1)
         pre = f's{it}_'
-        # Step 0 (pre-update weights) is held to the 1e-4 bar.  Later steps are a different matter:
-        # Adam's first updates are lr*sign(g), so the ~1 % gradient perturbation of a single kink
-        # event (see below) flips the update of ~0.2 % of the weights by 2*lr, which moves the next
-        # step's disparity by up to ~5e-3.  The reference has the same sensitivity (its own CPU runs
-        # reproduce to 1e-7 only because they are bit-identical programs); what is checked for later
-        # steps is therefore (a) outputs within 2e-2 after one update (a sanity bound that loosens with
-        # every further update of this deliberately untrained, fast-moving synthetic network) and (b)
-        # below, the weights in units of lr.
-        tol = TOL if it == 0 else (2e-2 if it == 1 else 1e-1)
+        # Step 0 (pre-update weights) is held to the 1e-4 bar.  Later steps are held to a MEASURED envelope instead of a guessed
+        # tolerance (tests/test_trajectory.py has the whole argument): the trajectory under Adam's first lr*sign(g) updates is
+        # ill-conditioned in any fp32 arithmetic, and how far the reference's own fp32 arithmetic is from exact arithmetic at
+        # step `it` is measured by running the oracle in float64 and in float32 (the oracle's fp32 run IS the reference's on
+        # these inputs: tests/test_oracle_golden.py).  d(HIP, reference) <= d(HIP, fp64) + d(reference, fp64) <= 3 * envelope.
+        if it == 0:
+            tol = TOL
+        else:
+            if envelope is None:
+                envelope = _fp32_envelope(B, steps, batch)
+            tol = 3 * envelope[it]['out'] + TOL
         _check_outputs(g, pre, outputs, tol)
         for k, v in losses.items():
             if it > 0 and ('smooth' in k or 'reg_loss' in k):
@@ -113,7 +140,7 @@ def test_adapt_matches_reference_golden(backend, case, B, steps):
                 assert abs(float(ref_grad.double().norm()) - gn) <= 1e-3 * gn + 1e-9, name      # bit-equal where the fixture was made; another host's BLAS: 1e-5 (1e-4 on the 1-element bias gradients, residues of cancelling sums)
                 assert float((ref_grad.reshape(-1)[:96] - torch.from_numpy(g[pre + 'gradslice/' + name])).abs().max()) <= 1e-3 * max(gn, 1e-6)
             assert r['flips'] <= 2e-4 * r['npix'] and r['cell_flips'] + r['clip_flips'] <= 1e-3 * r['npix']
-            for name, e_free, e_sel, norm, e_all, e_hip64, e_o64, e_bwd, e_bwd_t32 in r['rows']:
+            for name, e_free, e_sel, norm, e_all, e_hip64, e_o64, e_bwd, e_bwd_t32, e_bwd_p in r['rows']:
                 # same decisions: rounding of the two fp32 forwards, amplified (<= 2e-3); at the kernel path's forward point the
                 # backward arithmetic alone: 2e-4 (tests/test_backward_parity.py has the whole ladder)
                 assert e_all < 2e-3 and e_bwd < 3e-4, (name, e_free, e_sel, e_all, e_bwd)
@@ -127,7 +154,7 @@ def test_adapt_matches_reference_golden(backend, case, B, steps):
             ref = torch.from_numpy(g[pre + 'wslice/' + name])
             nbad += int(((wv - ref).abs() > 0.5e-4).sum())
             ntot += ref.numel()
-        assert nbad <= (0.01 if it == 0 else 0.10) * ntot, (it, nbad, ntot)
+        assert nbad <= (0.01 if it == 0 else 3 * envelope[it]['w_flipped'] + 0.01) * ntot, (it, nbad, ntot)
     # checkpoint layout: 160 params, Adam state on ids 62-89 and 152-159
     osd = p.optimizer.state_dict()
     assert sorted(osd['state'].keys()) == list(g['opt_state_ids'])

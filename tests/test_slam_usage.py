@@ -360,7 +360,9 @@ def test_descriptor_pass_is_memoised_for_the_single_triplet_forward(backend):
         p.engine.wait_training()
         log.append(p.engine.w.cpu().clone())
         runs[memo] = (log, (hits1, hits2, hits3, p.engine.memo_hits))
-    assert runs[True][1] == (1, 3, 3, 3) and runs[False][1] == (0, 0, 0, 0)
+    # (a memo serves ONE forward -- the frame's adapt() right behind the descriptor pass, slam.py:143-178; the predict() of frame 2
+    # recomputes: the content check is a stream synchronisation nobody else should pay)
+    assert runs[True][1] == (1, 2, 2, 2) and runs[False][1] == (0, 0, 0, 0)
     for a, b in zip(runs[True][0], runs[False][0]):
         assert torch.equal(a, b)
 

@@ -1,0 +1,134 @@
+"""Later-step parity as a MEASURED envelope.  The reference ships `adaptation_epochs: 5`
+(config/config_adapt.yaml:53): adapt() returns the forward of the FIFTH step (dpp.py:309-319), i.e. a point four Adam updates
+away from the weights both implementations started from.  Step 0 is held to 1e-4 elsewhere; for the later steps a fixed
+tolerance would be a guess, because the trajectory of this piecewise-smooth loss under Adam's first `lr * sign(g)` updates is
+ill-conditioned in ANY fp32 arithmetic.  So the yardstick is measured: the oracle is run in float64 (OraclePredictor.to_double)
+and in float32 on the same inputs and noise, and for every step s = 1..5 the HIP path must be as close to the float64
+trajectory as the reference's own fp32 arithmetic is:
+
+        d(HIP, fp64)  <=  2 * d(oracle fp32, fp64) + floor
+
+on the disparity, both pose matrices (relative L2), the loss and the updated weights (in units of lr: fraction of flipped
+updates and the mean distance).  The floor is the step-0 parity bar (1e-4 relative on outputs; 0.2 % flipped updates on
+weights: two fp32 implementations flip different near-zero gradient entries).
+
+The drift is a chaotic amplification (x10 ... x30 per step on this untrained synthetic network), so d(oracle fp32, fp64) is
+itself a SAMPLE: the fp32 oracle with its weights moved by one ulp (another legitimate fp32 realisation of the same
+arithmetic) lands at up to ~5x another distance from the same float64 trajectory (printed below), with a heavy tail: whether
+ONE near-zero pose-gradient component comes out with the other sign decides ~5000 weight updates at once.  Both sides are
+therefore sampled three times -- the plain weights and two last-bit perturbations (the same patterns for the oracle and the HIP
+path) -- and the rule is   median_k d(HIP_k, fp64)  <=  2 * max_k d(oracle fp32_k, fp64) + floor.   A HIP path whose arithmetic
+were systematically worse than fp32 (say 5x the drift) fails it at steps 1-3, where nothing has saturated yet.  Numbers are
+printed for profiles/r04_trajectory.txt."""
+import math
+
+import pytest
+import torch
+
+from clslam_hip import synth
+from clslam_hip.engine import TrainableLayout
+from emu_util import BACKENDS, use_backend
+from helpers import make_oracle, rel_l2
+from predictor_util import make_predictor
+
+STEPS = 5
+LR = 1e-4
+
+
+def _dist(a, b):
+    """distance of one recorded step from the float64 one"""
+    flipped = total = 0
+    mean_lr = 0.0
+    for name, wb in b['w'].items():
+        d = (a['w'][name].double() - wb.double()).abs()
+        flipped += int((d > 0.5 * LR).sum())
+        total += d.numel()
+        mean_lr += float(d.sum())
+    return {'disp0': rel_l2(a['disp0'], b['disp0']), 'T-1': rel_l2(a['T-1'], b['T-1']), 'T+1': rel_l2(a['T+1'], b['T+1']),
+            'loss': abs(a['loss'] - b['loss']) / abs(b['loss']), 'w_flipped': flipped / total, 'w_mean_lr': mean_lr / total / LR}
+
+
+def _hip_trajectory(p, batch, noises):
+    rec = []
+    for it in range(STEPS):
+        p.set_tie_break_noise(noises[it])
+        out, losses = p.adapt(None, {k: v.clone() for k, v in batch.items()}, steps=1)
+        eng = p.engine
+        w = {name: TrainableLayout.to_reference(eng.w[off:off + math.prod(shape)], shape).cpu().clone()
+             for name, off, shape in eng.layout.entries}
+        rec.append({'disp0': out['disp', 0].cpu().clone(), 'T-1': out['cam_T_cam', 0, -1].cpu().clone(),
+                    'T+1': out['cam_T_cam', 0, 1].cpu().clone(), 'loss': float(losses['loss']), 'w': w})
+    return rec
+
+
+FLOOR = {'disp0': 1e-4, 'T-1': 1e-4, 'T+1': 1e-4, 'loss': 1e-4, 'w_flipped': 2e-3, 'w_mean_lr': 5e-3}
+
+
+def _run(backend, H, W, B, seed, capsys):
+    use_backend(backend)
+    batch = synth.make_batch(B, H, W, seed=seed)
+    noises = [synth.make_noise(B, H, W, seed=seed + 20 + it) for it in range(STEPS)]
+    b64 = {k: (v.double() if v.is_floating_point() else v) for k, v in batch.items()}
+    n64 = [{s: v.double() for s, v in n.items()} for n in noises]
+    exact = make_oracle(H, W, B).to_double().trajectory(b64, n64, STEPS)
+    def perturb(modules, k):
+        """every parameter one ulp up or down (or left alone), by a fixed pseudo-random pattern"""
+        if not k:
+            return
+        gen = torch.Generator().manual_seed(1000 + k)
+        with torch.no_grad():
+            for m in modules.values():
+                for prm in torch.nn.Module.parameters(m):
+                    r = torch.randint(0, 3, prm.shape, generator=gen).to(prm.device)
+                    up = torch.nextafter(prm, torch.full_like(prm, float('inf')))
+                    dn = torch.nextafter(prm, torch.full_like(prm, float('-inf')))
+                    prm.copy_(torch.where(r == 0, dn, torch.where(r == 2, up, prm)))
+    realisations, hips = [], []
+    for k in range(3):
+        o = make_oracle(H, W, B)
+        perturb(o.models, k)
+        realisations.append(o.trajectory(batch, noises, STEPS))
+        p = make_predictor(H, W, B)
+        perturb(p.models, k)
+        hips.append(_hip_trajectory(p, batch, noises))
+    # the same five steps as ONE adapt(steps=5) call (frozen-feature reuse inside the call, one noise field for all five
+    # steps): the final forward is what the reference's shipped configuration returns -- bitwise the step-by-step run's
+    q = make_predictor(H, W, B)
+    q.set_tie_break_noise(noises[0])
+    out5, l5 = q.adapt(None, {k: v.clone() for k, v in batch.items()}, steps=STEPS)
+    r = make_predictor(H, W, B)
+    r.set_tie_break_noise(noises[0])
+    for _ in range(STEPS):
+        out1, l1 = r.adapt(None, {k: v.clone() for k, v in batch.items()}, steps=1)
+    assert torch.equal(out5['disp', 0], out1['disp', 0]) and torch.equal(l5['loss'], l1['loss'])
+    assert torch.equal(q.engine.w, r.engine.w)
+    lines, bad = [], []
+    for it in range(STEPS):
+        dhs = [_dist(h[it], exact[it]) for h in hips]
+        dos = [_dist(r[it], exact[it]) for r in realisations]
+        dh = {k: sorted(d[k] for d in dhs)[1] for k in dhs[0]}
+        do = {k: max(d[k] for d in dos) for k in dh}
+        lines.append(f'[{backend} {H}x{W} B={B}] step {it + 1}: ' + '  '.join(
+            f'{k} ' + ' / '.join(f'{d[k]:.1e}' for d in dhs) + ' (oracle fp32: ' + ' / '.join(f'{d[k]:.1e}' for d in dos) + ')' for k in dh))
+        for k in dh:
+            env = do[k]
+            if k == 'loss':
+                # ONE number: its distance from the float64 value comes out an order of magnitude smaller for one realisation
+                # than for another by chance (a sum of drifts of both signs).  It is held to the envelope of the smaller of
+                # the two pose-matrix drifts it is computed from as well.
+                env = max(env, min(do['T-1'], do['T+1']))
+            if dh[k] > 2 * env + FLOOR[k]:
+                bad.append((it + 1, k, dh[k], do[k]))
+    with capsys.disabled():
+        print('\n' + '\n'.join(lines))
+    assert not bad, bad
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_five_step_trajectory_stays_inside_the_fp32_envelope(backend, capsys):
+    _run(backend, 64, 128, 3, 31, capsys)
+
+
+@pytest.mark.gpu
+def test_five_step_trajectory_at_full_size(capsys):
+    _run('hip', 192, 640, 1, 33, capsys)
