@@ -256,10 +256,25 @@ def main():
         p.host_pose_output = not prev
         ms_other = timed(3)
         p.host_pose_output = prev
-        # ... and with the training step on the caller's stream (rounds 1-3: the first .cpu() waits for backward + Adam)
+        # ... and with the training step on the caller's stream (rounds 1-3: the first .cpu() waits for backward + Adam),
+        # on both boundaries (host outputs + caller's stream = round 3's opt-in fast path, for same-box comparison)
         p.engine.detached_training = False
         ms_attached = timed(3)
+        p.host_pose_output = not prev
+        ms_attached_other = timed(3)
+        p.host_pose_output = prev
         p.engine.detached_training = True
+        ms_att_dev, ms_att_host = (ms_attached_other, ms_attached) if prev else (ms_attached, ms_attached_other)
+        # the box's own host -> device rate for this dict (the frame is partly PCIe time and the boxes of the pool differ)
+        big = torch.empty(64 << 20, dtype=torch.uint8).pin_memory()
+        dbig = torch.empty_like(big, device=dev)
+        dbig.copy_(big, non_blocking=True)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            dbig.copy_(big, non_blocking=True)
+        sync()
+        h2d_gbs = 5 * big.numel() / (time.perf_counter() - t0) / 1e9
         up = [k for k in host if isinstance(host[k], torch.Tensor)] if p.upload_all_inputs else [k for k in p.UPLOAD_FIRST + p.UPLOAD_REST if k in host]
         ms_dev, ms_host = (ms_other, ms_e2e) if prev else (ms_e2e, ms_other)
         e2e = {'ms_per_frame': round(ms_e2e, 3), 'frames_per_s': round(1e3 / ms_e2e, 2),
@@ -268,7 +283,8 @@ def main():
                'h2d_tensors': len(up), 'of_tensors_in_sample_dict': len(host),
                'ms_per_frame_with_device_outputs': round(ms_dev, 3),
                'ms_per_frame_with_host_outputs': round(ms_host, 3),
-               'ms_per_frame_step_on_callers_stream': round(ms_attached, 3),
+               'ms_per_frame_step_on_callers_stream': {'device_outputs': round(ms_att_dev, 3), 'host_outputs_r03_fast_path': round(ms_att_host, 3)},
+               'h2d_gbytes_per_s_of_this_box': round(h2d_gbs, 1),
                'includes': 'H2D of the whole sample dict from pinned host memory (dpp.py:916-917; copy stream, network inputs '
                            'first, entries the path never reads last), adapt(), cam_T_cam[0] and the loss scalars on the host '
                            '(slam.py:181-188)' + (', loop-closure encoder forward (slam.py:223)' if lcd_enc is not None else '')}

@@ -190,6 +190,15 @@ class Engine:
         self._memo = None
         self.memo_hits = 0
         self._pending_reduce = None
+        # Data-parallel gradient exchange in BUCKETS: the flat arena is cut into three contiguous
+        # ranges in the order their gradients complete in the backward -- the pose decoder (its short backward runs beside the
+        # depth decoder's), the depth decoder's levels 3..0 + disparity heads, and last the two 512/256-channel convolutions
+        # of level 4 (53 % of the payload: they are the END of the data-gradient chain).  Each range is reduced from its
+        # partials and all-reduced on the tail stream as soon as its last weight-gradient kernel has been enqueued, so all but
+        # the last all-reduce run underneath the rest of the backward; Adam follows once.  The sequence of collectives
+        # (three all-reduces, same slices, same order) is the same on every rank whatever its workspace / overlap state.
+        self.grad_buckets = int(os.environ.get('CLSLAM_GRAD_BUCKETS', '3'))
+        self.grads_synced = False
         self.tail_stream = pool.get('tail')
         self._tail_event = None       # optimizer step in flight on tail_stream
         self._tail_open = False       # backward() left its reduction on tail_stream; adam() closes it
@@ -876,10 +885,33 @@ class Engine:
         if plan.colsum is not None:
             ops.colsum(dz, plan.colsum, out_shape[0] * out_shape[1] * out_shape[2], cout)
 
-    def backward(self, B: int, defer_reduce: bool = False) -> None:
+    def bucket_ranges(self):
+        """[(name, first float, end float)] of the gradient buckets in backward-COMPLETION order (contiguous in the arena)."""
+        off = self.layout.offset
+        a_end, c_start = off['depth_decoder/upconv_3_0.conv.conv.weight'], off['pose_decoder/squeeze.weight']
+        if self.grad_buckets >= 3:
+            return [('pose', c_start, self.layout.size), ('mid', a_end, c_start), ('deep', 0, a_end)]
+        if self.grad_buckets == 2:
+            return [('early', a_end, self.layout.size), ('deep', 0, a_end)]
+        return [('all', 0, self.layout.size)]
+
+    def _bucket_sync(self, t, name: str, events, allreduce) -> None:
+        """tail stream: wait for the bucket's producers, reduce its partials into the arena, all-reduce its slice."""
+        tail = self.tail_stream
+        for ev in events:
+            tail.wait_event(ev)
+        table, n, lo, hi = t.bucket_tables[name]
+        with torch.cuda.stream(tail):
+            ops.reduce_multi(table, n, self._g)
+            allreduce(self._g[lo:hi])
+
+    def backward(self, B: int, defer_reduce: bool = False, allreduce=None) -> None:
         """dL/d(trainable arena) for the last training forward; fills self._g (dpp.py:312).
         defer_reduce: the caller promises that adam() follows directly (adapt(), single GPU): the batched reduction of the
-        gradient partials is left to adam(), which fuses it with the update; self._g is complete after THAT launch."""
+        gradient partials is left to adam(), which fuses it with the update; self._g is complete after THAT launch.
+        allreduce: data-parallel mode -- callable(slice of the gradient arena) that sum-all-reduces it over the ranks on
+        torch's current stream.  With it (and grad_buckets > 1) backward() exchanges the gradients itself, bucket by bucket
+        (see __init__); self.grads_synced tells the caller so."""
         ws = self._ws[B]
         t = ws.train
         c = ws.ctx
@@ -911,6 +943,11 @@ class Engine:
             self.inputs_released = torch.cuda.Event()
             self.inputs_released.record(self._main)
         side = self.side_stream if (self.use_side_stream and self.side_stream is not None) else None
+        bucketed = allreduce is not None and self.grad_buckets > 1
+        # overlapped exchange: needs the tail stream, the side / wgrad streams and the per-bucket tables of a previous backward
+        overlap = (bucketed and self._use_tail() and side is not None and wg is not None
+                   and getattr(t, 'bucket_tables', None) is not None)
+        self.grads_synced = False
         if side is not None:
             main = self._main
             side.wait_stream(main)
@@ -918,7 +955,12 @@ class Engine:
                 side.wait_event(t.wt_ready)     # transposed pose_0 / pose_1 weights
             with self._on(side):
                 self._backward_pose_decoder(ws, t, B, t.side)
-            self._backward_depth_decoder(ws, t, B)
+            if overlap and self.grad_buckets >= 3:
+                ev = torch.cuda.Event()
+                ev.record(side)                 # the pose decoder's three weight gradients + pose_2's are complete behind this
+                self._bucket_sync(t, 'pose', [ev], allreduce)
+            self._backward_depth_decoder(ws, t, B, mid_done=(lambda evs: self._bucket_sync(
+                t, 'mid' if self.grad_buckets >= 3 else 'early', evs, allreduce)) if overlap else None)
             main.wait_stream(side)
         else:
             self._backward_depth_decoder(ws, t, B)
@@ -931,8 +973,39 @@ class Engine:
                 sl = self._slot(self._g, key, n)
                 t.items.append((sl, sl, n, 1))
             t.table = ops.make_reduce_table(t.items, self.device)
+            # the same items grouped by the bucket their destination lies in (every item reduces independently, in a fixed
+            # order: three launches give bitwise the single launch's arena)
+            base = self._g.data_ptr()
+            t.bucket_tables = {}
+            for name, lo, hi in self.bucket_ranges():
+                its = [it for it in t.items if lo <= (it[1].data_ptr() - base) // 4 < hi]
+                t.bucket_tables[name] = (ops.make_reduce_table(its, self.device), len(its), lo, hi)
+            assert sum(v[1] for v in t.bucket_tables.values()) == len(t.items)
         self._pending_reduce = None
-        if defer_reduce and self.fuse_adam and not self.data_parallel and not self._capturing and not self._use_tail():
+        if bucketed:
+            ranges = self.bucket_ranges()
+            if overlap:
+                # the earlier buckets went out during the backward; the last one (level 4) is complete on the main stream now
+                name, lo, hi = ranges[-1]
+                self.tail_stream.wait_stream(self._main)
+                self._bucket_sync(t, name, [], allreduce)
+                self._tail_open = True
+            else:
+                # no overlap possible (first backward of this workspace, no tail / side streams, instrumented run): one
+                # reduction, then the SAME sequence of collectives on the same slices
+                if self._use_tail():
+                    self.tail_stream.wait_stream(self._main)
+                    with torch.cuda.stream(self.tail_stream):
+                        ops.reduce_multi(t.table, len(t.items), self._g)
+                        for name, lo, hi in ranges:
+                            allreduce(self._g[lo:hi])
+                    self._tail_open = True
+                else:
+                    ops.reduce_multi(t.table, len(t.items), self._g)
+                    for name, lo, hi in ranges:
+                        allreduce(self._g[lo:hi])
+            self.grads_synced = True
+        elif defer_reduce and self.fuse_adam and not self.data_parallel and not self._capturing and not self._use_tail():
             self._pending_reduce = (t.table, len(t.items))
         elif self._use_tail():
             # the partial buffers are complete on the current stream; the reduction, the all-reduce (caller, under
@@ -969,7 +1042,7 @@ class Engine:
             t.wt_table = ops.transpose_table(items)
         ops.weight_transpose_multi(t.wt_table, self._w)
 
-    def _backward_depth_decoder(self, ws, t, B: int) -> None:
+    def _backward_depth_decoder(self, ws, t, B: int, mid_done=None) -> None:
         """dgrad chain (critical path) on the current stream; every weight/bias gradient is independent
         of the rest of the chain once its dz exists, so those run on a third stream (`wg_stream`)."""
         H, W = self.H, self.W
@@ -1045,6 +1118,15 @@ class Engine:
                 wt = t.wt_dec[i, 0]
                 dxp_in = t.dxp[0][:B * (h2 + 2) * (w2 + 2) * cin0].view(B, h2 + 2, w2 + 2, cin0)
                 ops.conv2d(t.dz[i, 0], wt, dxp_in, ksize=3, pad=2)
+            if i == 3 and mid_done is not None:
+                # every gradient of levels 0..3 and of the four disparity heads has been enqueued: weight gradients on the
+                # wgrad streams, bias partials by the folds on the main stream.  Level 4 (53 % of the arena) is still to come.
+                evs = []
+                for st in [main] + [x for x in wg_streams if x is not None]:
+                    ev = torch.cuda.Event()
+                    ev.record(st)
+                    evs.append(ev)
+                mid_done(evs)
         if wg is not None:
             main.wait_stream(wg)
 

@@ -19,7 +19,7 @@ LIB_DIR = CSRC.parent / 'lib'
 OBJ_DIR = CSRC / 'build'
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-DCLSLAM_DEVICE_BUILD=1',
-         '-I', str(CSRC / 'include'), '-Wno-unused-result']
+         '-I', str(CSRC / 'include'), '-Wno-unused-result'] + os.environ.get('CLSLAM_HIPCC_EXTRA', '').split()
 
 
 def source_id() -> str:

@@ -213,7 +213,11 @@ __device__ __forceinline__ void wg_barrier_keep_dma() {
 
 // 1/x to 1 ulp (v_rcp_f32) -- for the SSIM / projection quotients of the loss kernels, where an IEEE
 // division costs ~10 instructions and the last ulp is far below the 1e-4 parity bar
+#ifdef CLSLAM_EXACT_DIV      // diagnostic builds only (tools/diag_pose.py): IEEE division in place of v_rcp_f32
+__device__ __forceinline__ float fast_rcp(float x) { return 1.f / x; }
+#else
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+#endif
 
 // value of lane (lane ^ mask)
 __device__ __forceinline__ float wave_shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }

@@ -707,13 +707,18 @@ class DepthPosePrediction:
     def _backward(self, inputs: Dict[Any, Tensor]) -> None:
         B = inputs['rgb_aug', 0, 0].shape[0]
         # (adapt() calls optimizer.step() right after this: on a single GPU the reduction is fused into that launch)
-        self.engine.backward(B, defer_reduce=self._dp is None)
+        self.engine.backward(B, defer_reduce=self._dp is None, allreduce=self._allreduce if self._dp is not None else None)
         self._reduce_gradients()
 
+    def _allreduce(self, t: Tensor) -> None:
+        """sum over the ranks, on torch's current stream (the engine calls it per gradient bucket on its tail stream)"""
+        self._dp['dist'].all_reduce(t, group=self._dp['group'])
+
     def _reduce_gradients(self) -> None:
-        if self._dp is not None:
+        if self._dp is not None and not self.engine.grads_synced:
             with self.engine.training_stream():     # the tail stream when the engine left the reduction there
                 self._dp['dist'].all_reduce(self.engine._g, group=self._dp['group'])
+        self.engine.grads_synced = False
 
 
 def _null_context():

@@ -37,8 +37,10 @@ def _lcd_weights():
     return _weights()[1]
 
 
-def _dp_worker(rank, world, port, H, W, counts, steps, frames, lcd, async_tail, out_dir):
+def _dp_worker(rank, world, port, H, W, counts, steps, frames, lcd, async_tail, out_dir, buckets=None, tag=''):
     os.environ['CLSLAM_ASYNC_TAIL'] = '1' if async_tail else '0'
+    if buckets is not None:
+        os.environ['CLSLAM_GRAD_BUCKETS'] = str(buckets)
     dist = _setup(rank, world, port)
     from clslam_hip import synth
     from predictor_util import make_predictor
@@ -79,7 +81,7 @@ def _dp_worker(rank, world, port, H, W, counts, steps, frames, lcd, async_tail, 
     torch.save({'in_sync': in_sync, 'diverged_seen': diverged_seen, 'full_depth': cpu(everything['depth', 0]),
                 'full_T': cpu(everything['cam_T_cam', 0, -1]), 'g': cpu(p.engine.g), 'w': cpu(p.engine.w), 'm': cpu(p.engine.m),
                 'loss': {k: cpu(v).clone() for k, v in losses.items()}, 'T': cpu(out['cam_T_cam', 0, 1]), 'feats': feats, 'first': first},
-               Path(out_dir) / f'rank{rank}_{int(async_tail)}.pt')
+               Path(out_dir) / f'rank{rank}_{int(async_tail)}{tag}.pt')
     dist.barrier()
     dist.destroy_process_group()
 
@@ -138,6 +140,31 @@ def test_two_ranks_on_one_gpu_equal_single_rank(tmp_path, H, W, counts, lcd):
         for f in range(frames):
             ref = enc(synth.make_batch(B, H, W, seed=4 + f)['rgb', 1, 0][:1].cuda()).cpu()
             assert ref.shape == (1, 576) and torch.equal(r[0, 1]['feats'][f], ref)
+
+
+@pytest.mark.timeout(1500)
+def test_bucketed_gradient_exchange_is_bitwise_the_single_all_reduce(tmp_path):
+    """SURVEY.md section 5 (K19, "bucketed / overlapped"): three all-reduces in backward-completion order, the first two
+    underneath the rest of the backward on the tail stream (Engine.grad_buckets), against ONE all-reduce of the whole arena
+    after the backward.  Two ranks (a + b is the same number in either order), 3 + 2 triplets at 192x640, three frames of
+    adapt(steps=2) -- the first backward of a workspace exchanges without overlap, the later ones overlapped: gradients,
+    weights, moments and outputs are bitwise equal, with the asynchronous tail and without it."""
+    sys.path.insert(0, str(ROOT / 'tests'))
+    H, W, counts = 192, 640, [3, 2]
+    runs = {}
+    for i, (buckets, tail) in enumerate([(1, True), (3, True), (2, True), (3, False)]):
+        port = 29500 + (os.getpid() % 2000) + 21 + 2 * i
+        tag = f'_b{buckets}'
+        mp.start_processes(_dp_worker, args=(2, port, H, W, counts, 2, 3, False, tail, str(tmp_path), buckets, tag), nprocs=2,
+                           join=True, start_method='spawn')
+        runs[buckets, tail] = [torch.load(tmp_path / f'rank{k}_{int(tail)}{tag}.pt') for k in (0, 1)]
+    ref = runs[1, True]
+    for key, got in runs.items():
+        for k in (0, 1):
+            assert torch.equal(got[0]['g'], got[1]['g']) and got[k]['in_sync']
+            for name in ('g', 'w', 'm', 'full_depth', 'T'):
+                assert torch.equal(ref[k][name], got[k][name]), (key, k, name)
+            assert torch.equal(ref[k]['first']['g'], got[k]['first']['g'])
 
 
 # ---- CoVIO asynchronous predict / adapt mode ------------------------------------------------------------------------
