@@ -133,7 +133,7 @@ _SIGNATURES = {
     'clslam_diversity_commit': [fptr, fptr, i32, C.c_void_p, i32, i32, i32, i32, C.c_float, fptr, fptr, C.c_void_p,
                                 fptr, C.c_void_p],
 }
-_RESTYPES = {'clslam_last_error': C.c_char_p}
+_RESTYPES = {'clslam_last_error': C.c_char_p, 'clslam_build_id': C.c_char_p}
 
 
 class ClslamError(RuntimeError):
@@ -148,8 +148,9 @@ class Library:
                 '(hipcc --offload-arch=gfx950). There is no CPU fallback for this path.')
         self.path = Path(path)
         self.cdll = C.CDLL(str(path))
-        self.cdll.clslam_last_error.restype = C.c_char_p
-        self.cdll.clslam_last_error.argtypes = []
+        for name, rt in _RESTYPES.items():
+            fn = getattr(self.cdll, name)
+            fn.restype, fn.argtypes = rt, []
         for name, argtypes in _SIGNATURES.items():
             fn = getattr(self.cdll, name)  # AttributeError if the symbol is not exported
             fn.argtypes = argtypes
@@ -186,18 +187,21 @@ def install_library_for_tests(path) -> Library:
 
 
 def exported_symbols():
-    return ['clslam_last_error'] + list(_SIGNATURES)
+    return list(_RESTYPES) + list(_SIGNATURES)
 
 
 def build_id() -> str:
-    """Identity of the kernel sources the loaded library was built from (written by csrc/build.py at link time), checked
-    against the sources present: 'stale:<lib>/<src>' when they differ (a library older than its sources)."""
-    import importlib.util
+    """Identity of the kernel sources the LOADED library was built from (embedded at link time by csrc/build.py, read through
+    clslam_build_id()).  Where the sources are present it is checked against them: 'stale:<lib>/<src>' when they differ (a
+    library older than its sources); an install that ships only the .so just reports the embedded id."""
+    built = get_lib().cdll.clslam_build_id().decode()
+    built = built.split(':', 1)[1] if built.startswith('clslam-build-id:') else built
     csrc = Path(__file__).resolve().parents[1] / 'csrc'
+    if not (csrc / 'build.py').exists():
+        return built
+    import importlib.util
     spec = importlib.util.spec_from_file_location('_clslam_build', csrc / 'build.py')
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     src = mod.source_id()
-    f = Path(__file__).resolve().parents[1] / 'lib' / 'libclslam_hip.build_id'
-    built = f.read_text().strip() if f.exists() else 'unknown'
     return built if built == src else f'stale:{built}/{src}'

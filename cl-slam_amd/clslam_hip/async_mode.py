@@ -121,10 +121,21 @@ class AsyncAdaptation:
                 self._work = None
             try:
                 out = self.p.adapt(online_data, training_data if training_data is not None else online_data, steps=steps)
-            except Exception:
-                # e.g. RuntimeError('NaN loss'): release the inference replica with an abort marker at its next receive
-                self._post(frame, abort=True)
-                self.flush()
+            except Exception as exc:
+                # Release the inference replica with an abort marker at its next receive -- but only when EVERY trainer is on
+                # this path: the marker travels by a collective over `group`, which all trainers have to post.  That is the
+                # case for RuntimeError('NaN loss') (the loss scalars are all-reduced before the check of dpp.py:1115-1118, so
+                # all trainers raise at the same step; the marker itself is the leader's, the broadcast source) and trivially
+                # with a single trainer.  A failure of ONE trainer among several (bad input, out of memory) is not agreed
+                # on: posting would leave an unmatched collective behind while the peers sit in the gradient all-reduce --
+                # this trainer just raises, the peers run into their communicator's timeout / `transfer_timeout_s`.
+                agreed = self.world == 2 or (isinstance(exc, RuntimeError) and 'NaN loss' in str(exc))
+                if agreed:
+                    try:
+                        self._post(frame, abort=True)
+                        self.flush()
+                    except Exception:       # noqa: BLE001 -- the step's own failure is the one to report
+                        pass
                 raise
         else:
             self._install(block=False)

@@ -40,20 +40,40 @@ def _deps_mtime() -> float:
     return max(h.stat().st_mtime for h in hs)
 
 
+def _embedded_id(lib: Path) -> str:
+    """the id a built library carries (clslam_build_id), without loading it: the string sits in .rodata behind a marker"""
+    try:
+        data = lib.read_bytes()
+        i = data.find(b'clslam-build-id:')
+        return data[i + 16:i + 32].decode() if i >= 0 else ''
+    except OSError:
+        return ''
+
+
 def build(force: bool = False, verbose: bool = True) -> Path:
     LIB_DIR.mkdir(exist_ok=True)
     OBJ_DIR.mkdir(exist_ok=True)
     srcs = sorted(CSRC.glob('*.hip'))
     hdr_m = _deps_mtime()
+    sid = source_id()
+    lib = LIB_DIR / 'libclslam_hip.so'
+    # The id is a statement about the library: it is compiled INTO it (capi.hip, -DCLSLAM_BUILD_ID) whenever anything is
+    # rebuilt, and a library whose embedded id is not the id of the sources present is rebuilt whatever the mtimes say
+    # (sources restored with older timestamps, an object cache of another checkout).
+    if lib.exists() and _embedded_id(lib) != sid:
+        force = True
     jobs = []
     for s in srcs:
         o = OBJ_DIR / (s.stem + '.o')
         if force or not o.exists() or o.stat().st_mtime < max(s.stat().st_mtime, hdr_m):
             jobs.append((s, o))
+    if jobs and not any(s.stem == 'capi' for s, _ in jobs):
+        jobs.append((CSRC / 'capi.hip', OBJ_DIR / 'capi.o'))        # re-stamp
 
     def cc(job):
         s, o = job
-        cmd = [HIPCC, *FLAGS, '-c', str(s), '-o', str(o)]
+        extra = [f'-DCLSLAM_BUILD_ID="clslam-build-id:{sid}"'] if s.stem == 'capi' else []
+        cmd = [HIPCC, *FLAGS, *extra, '-c', str(s), '-o', str(o)]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f'hipcc failed for {s.name}:\n{r.stderr[-4000:]}')
@@ -63,7 +83,6 @@ def build(force: bool = False, verbose: bool = True) -> Path:
 
     with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
         list(ex.map(cc, jobs))
-    lib = LIB_DIR / 'libclslam_hip.so'
     objs = [str(OBJ_DIR / (s.stem + '.o')) for s in srcs]
     if jobs or not lib.exists():
         r = subprocess.run([HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', str(lib), *objs],
@@ -72,7 +91,7 @@ def build(force: bool = False, verbose: bool = True) -> Path:
             raise RuntimeError(f'link failed:\n{r.stderr[-4000:]}')
         if verbose:
             print(f'[link] {lib}', flush=True)
-    (LIB_DIR / 'libclslam_hip.build_id').write_text(source_id() + '\n')
+        (LIB_DIR / 'libclslam_hip.build_id').write_text(sid + '\n')     # (a readable copy; the library itself is the authority)
     return lib
 
 

@@ -76,5 +76,11 @@ extern "C" int clslam_conv_profile_end(float* ms, int capacity, int* count) {
 }
 
 extern "C" int clslam_version(void) { return 100; }
+// identity of the kernel sources this library was LINKED from (csrc/build.py passes it when it compiles this file, which it
+// does whenever any object is rebuilt): read from the loaded library, not from a file beside it
+#ifndef CLSLAM_BUILD_ID
+#define CLSLAM_BUILD_ID "unstamped"
+#endif
+extern "C" const char* clslam_build_id(void) { return CLSLAM_BUILD_ID; }
 extern "C" const char* clslam_last_error(void) { return clslam::g_err; }
 extern "C" int clslam_is_device_build(void) { return CLSLAM_DEVICE_BUILD; }

@@ -40,6 +40,9 @@ extern "C" {
 /* Library identification / error text (thread-local). */
 int clslam_version(void);
 const char* clslam_last_error(void);
+/* 16 hex digits identifying the kernel sources the library was built from (csrc/build.py source_id()); "unstamped" for a
+ * build that did not go through build.py.  bench.py pairs its timings with counter files of the same id only.           */
+const char* clslam_build_id(void);
 /* 1 when the library was built from the HIP sources for gfx950, 0 for the CPU emulator used
  * by the host-logic tests (tests/emu); the product loader refuses anything but 1. */
 int clslam_is_device_build(void);

@@ -58,8 +58,8 @@ def attributed_gradient_errors(p, batch, noise, dev):
     selection; and with the kernel path's bilinear cells and border-clip flags imposed on the oracle's written-out sampler
     as well (clslam_warp_cells_pyramid -> oracle.functional.grid_sample_border).  Returns a dict with the flip counts,
     the rows (name, e_free, e_same_selection, norm, e_same_decisions, kernels vs float64 oracle on those decisions, torch fp32
-    vs the same, kernels vs float64 at the kernel path's forward point, torch fp32 vs the same) and the free oracle's
-    losses / gradients."""
+    vs the same, kernels vs float64 at the kernel path's forward point, torch fp32 vs the same, and both once more with the
+    kernel path's rounded projection matrices part of that point) and the free oracle's losses / gradients."""
     import math
     from clslam_hip import ops
     from clslam_hip.engine import TrainableLayout
@@ -147,9 +147,11 @@ def attributed_gradient_errors(p, batch, noise, dev):
     # sensitive quantity of the step to exactly that
     point_p = {**point, **{('P', f): ws.P[fi].detach().cpu() for fi, f in enumerate((-1, 1))}}
     exact_pp = exact_run(point_p)
+    fp32_pp = exact_run(point_p, double=False)
     rows = [(name, rel_l2(hip[name], ref[name]), rel_l2(hip[name], forced[name]), float(ref[name].norm()),
              rel_l2(hip[name], forced3[name]), rel_l2(hip[name], exact[name]), rel_l2(forced3[name], exact[name]),
-             rel_l2(hip[name], exact_pt[name]), rel_l2(fp32_pt[name], exact_pt[name]), rel_l2(hip[name], exact_pp[name])) for name in hip]
+             rel_l2(hip[name], exact_pt[name]), rel_l2(fp32_pt[name], exact_pt[name]), rel_l2(hip[name], exact_pp[name]),
+             rel_l2(fp32_pp[name], exact_pp[name])) for name in hip]
     return dict(flips=flips, npix=4 * B * H * W, gap=worst_gap, rows=rows, cell_flips=cell_flips, clip_flips=clip_flips, far_cells=far_cells, sign_flips=sign_flips,
                 oracle_losses=ol, oracle_grads=ref, hip_grads=hip)
 
@@ -162,10 +164,10 @@ def report_attribution(tag, r) -> None:
           f"selection + cells + clips {max(x[4] for x in rows):.2e}; against the float64 oracle on those decisions: kernels "
           f"{max(x[5] for x in rows):.2e}, torch fp32 {max(x[6] for x in rows):.2e}; the same at the kernel path's forward point with "
           f"its {r['sign_flips']} differing L1 signs imposed (backward arithmetic only): kernels {max(x[7] for x in rows):.2e}, torch fp32 {max(x[8] for x in rows):.2e}; "
-          f"with the kernel path's rounded projection matrices part of that point: kernels {max(x[9] for x in rows):.2e}")
+          f"with the kernel path's rounded projection matrices part of that point: kernels {max(x[9] for x in rows):.2e}, torch fp32 {max(x[10] for x in rows):.2e}")
     shown = sorted(rows, key=lambda x: -x[1])[:4]
     shown += [x for x in sorted(rows, key=lambda x: -x[4])[:3] if x not in shown]
     shown += [x for x in sorted(rows, key=lambda x: -x[7])[:2] if x not in shown]
     for x in shown:
         print(f'    {x[0]:44s} free {x[1]:.2e}  same selection {x[2]:.2e}  + cells/clips {x[4]:.2e}   vs float64: kernels {x[5]:.2e}  '
-              f'torch fp32 {x[6]:.2e}   at the same forward point: kernels {x[7]:.2e}  torch fp32 {x[8]:.2e}   + same P: kernels {x[9]:.2e}')
+              f'torch fp32 {x[6]:.2e}   at the same forward point: kernels {x[7]:.2e}  torch fp32 {x[8]:.2e}   + same P: kernels {x[9]:.2e}  torch fp32 {x[10]:.2e}')

@@ -15,8 +15,9 @@ residual demonstrated instead of asserted:
       kernels and torch's own fp32 sit at comparable distances from it -- and most of that distance is not the backward
       pass at all but the 1e-7-level rounding of the FORWARD pass (pose matrices, disparities), which this loss amplifies
       because it shifts every sample of a frame coherently;
-  (e) so the float64 oracle is finally evaluated AT the kernel path's forward point: the backward arithmetic of the kernels
-      alone is then as close to exact as torch's fp32 autograd is (<= 5e-4 on all 36 tensors, 192x640, B = 1 and B = 5).
+  (e) so the float64 oracle is finally evaluated AT the kernel path's forward point (its disparities, pose matrices and the
+      rounded projection matrices it samples with): the backward arithmetic of the kernels alone is then as close to exact as
+      torch's fp32 autograd is (<= 5e-4 on all 36 tensors, 192x640, B = 1 and B = 5).
 
 64x128, B=2 on the emulator and on the GPU; 192x640, B=1 and B=5 (the benchmark minibatch) on the GPU."""
 import pytest
@@ -48,7 +49,7 @@ def test_gradients_match_oracle_and_the_residual_is_selection_flips(backend, cap
     assert r['flips'] <= 2e-4 * r['npix'] and r['gap'] < 5e-6, (r['flips'], r['gap'])
     assert r['cell_flips'] + r['clip_flips'] <= 1e-3 * r['npix']
     rows = r['rows']
-    for name, e_free, e_forced, norm, e_all, e_hip64, e_o64, e_bwd, e_bwd_t32, e_bwd_p in rows:
+    for name, e_free, e_forced, norm, e_all, e_hip64, e_o64, e_bwd, e_bwd_t32, e_bwd_p, e_bwd_p_t32 in rows:
         assert e_free < 5e-2, (name, e_free)                 # full tensors (not norms / slices); dominated by the flips:
         assert e_forced < 1e-3, (name, e_forced)             # ... this is what is left once the selection is the same (4.9e-4)
         assert e_all < 1e-3, (name, e_all)                   # ... and with the sampler's decisions imposed as well
@@ -57,11 +58,16 @@ def test_gradients_match_oracle_and_the_residual_is_selection_flips(backend, cap
         assert max(x[2] for x in rows) < 0.2 * max(x[1] for x in rows)
 
 
-# all 36 tensors, same decisions, same forward point, against the float64 oracle.  Measured on the MI355X: B = 1 1.7e-4
-# (torch's own fp32: 1.5e-4), B = 5 7.4e-4 (3.7e-4).  Before the sampling position became one contraction-free chain shared by
-# forward, backward and read-out (geometry_dev.h) B = 5 stood at 2e-3 ... 5e-3: two pixels per scale whose sample lay within
-# an ulp of a cell boundary were differentiated in the neighbouring cell.
-FULL_SIZE_TOL = {1: 5e-4, 5: 2e-3}
+# all 36 tensors, same decisions, same forward point -- disparities, pose matrices AND the rounded projection matrices (K T)[:3]
+# the kernels actually sample with -- against the float64 oracle.  Measured on the MI355X: B = 1 1.4e-4 (torch's own fp32 at that
+# point: 1.5e-4), B = 5 4.3e-4 (torch fp32 the same level: profiles/r04_pose_gradient.txt takes the pose path apart sample by
+# sample -- dL/dP kernels 2.6e-5 ... 3.1e-4 / torch 2.4e-5 ... 3.4e-4, the pose chain of pose_bwd alone 7e-8).  Round 3 listed
+# 7.4e-4 for the pose decoder here: that was the ulp-level difference between the kernel path's fp32 product K T and the
+# oracle's float64 one (a coherent 1e-5 px shift of every sample of a frame), i.e. forward rounding, not backward arithmetic.
+# Before the sampling position became one contraction-free chain shared by forward, backward and read-out (geometry_dev.h)
+# B = 5 stood at 2e-3 ... 5e-3: two pixels per scale whose sample lay within an ulp of a cell boundary were differentiated in
+# the neighbouring cell.
+FULL_SIZE_TOL = {1: 5e-4, 5: 5e-4}
 MEASURED = {1: dict(flips=15, cells=200, signs=10, e_free=1e-2, e_all=2.5e-3),
             5: dict(flips=45, cells=1000, signs=40, e_free=0.1, e_all=2.5e-2)}
 
@@ -83,7 +89,7 @@ def test_gradients_full_size_on_gpu(capsys, B):
     assert r['cell_flips'] + r['clip_flips'] <= lim['cells'], (r['cell_flips'], r['clip_flips'])
     assert r['far_cells'] == 0, r['far_cells']
     assert r['sign_flips'] <= lim['signs'], r['sign_flips']
-    for name, e_free, e_forced, norm, e_all, e_hip64, e_o64, e_bwd, e_bwd_t32, e_bwd_p in r['rows']:
+    for name, e_free, e_forced, norm, e_all, e_hip64, e_o64, e_bwd, e_bwd_t32, e_bwd_p, e_bwd_p_t32 in r['rows']:
         assert e_free < lim['e_free'], (name, e_free)        # measured 2.5e-3 (B = 1) / 5.1e-2 (B = 5, 20 flipped selections)
         assert e_all < lim['e_all'], (name, e_all)           # the oracle's OWN forward, same selection / cells / clips: 1.1e-3 / 1.3e-2
-        assert e_bwd < FULL_SIZE_TOL[B], (name, e_bwd, e_bwd_t32)
+        assert e_bwd_p < FULL_SIZE_TOL[B], (name, e_bwd_p, e_bwd_p_t32, e_bwd, e_bwd_t32)
