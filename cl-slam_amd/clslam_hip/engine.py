@@ -662,9 +662,15 @@ class Engine:
         side = self.side_stream if (self.use_side_stream and self.side_stream is not None) else None
         id_ready = None
         wg = self.wg_stream if (self.use_side_stream and self.wg_stream is not None) else None
-        if wg is not None:
-            # the wgrad stream idles during the forward: the input-only work runs there, off the critical path
-            wg.wait_stream(self._main)
+        # the 1x1 downsample convolutions of both encoders go to the wgrad stream (idle during the forward once the identity
+        # maps are out) -- for a single triplet only, where the step is a chain of dependent 5-15 us launches (K = 0, 192x640:
+        # 1.454 -> 1.403 ms per frame incl. read-back).  At B = 5 the chip is throughput-bound and the six fork/join event
+        # pairs cost more than the launches they hide (3.311 -> 3.377 ms): CLSLAM_DS_AUX=1 / 0 forces it on / off.
+        ds_mode = os.environ.get('CLSLAM_DS_AUX', 'auto')
+        ds_aux = wg if ((ds_mode == '1' or (ds_mode == 'auto' and B == 1)) and not self._capturing) else None
+
+        def enqueue_identity():
+            nonlocal have_noise, id_ready
             if inputs_ready is not None:
                 wg.wait_event(inputs_ready[3])
             # (injected / captured noise is written by torch ops: they need torch's current stream switched)
@@ -672,12 +678,17 @@ class Engine:
                 have_noise = identity_and_noise()
             id_ready = torch.cuda.Event()
             id_ready.record(wg)
-        # the 1x1 downsample convolutions of both encoders go to the wgrad stream (idle during the forward once the identity
-        # maps are out) -- for a single triplet only, where the step is a chain of dependent 5-15 us launches (K = 0, 192x640:
-        # 1.454 -> 1.403 ms per frame incl. read-back).  At B = 5 the chip is throughput-bound and the six fork/join event
-        # pairs cost more than the launches they hide (3.311 -> 3.377 ms): CLSLAM_DS_AUX=1 / 0 forces it on / off.
-        ds_mode = os.environ.get('CLSLAM_DS_AUX', 'auto')
-        ds_aux = wg if ((ds_mode == '1' or (ds_mode == 'auto' and B == 1)) and not self._capturing) else None
+        have_noise = False
+        # A host minibatch still crossing PCIe: the identity maps read the un-augmented frames, i.e. they wait for the WHOLE
+        # upload -- and so would everything queued behind them on the wgrad stream.  With the downsample convolutions on that
+        # stream (single triplets) the first stage entry of the depth encoder must not inherit that wait: the
+        # identity maps then go out AFTER the networks' launches.
+        defer_identity = wg is not None and ds_aux is not None and inputs_ready is not None and not reuse
+        if wg is not None:
+            # the wgrad stream idles during the forward: the input-only work runs there, off the critical path
+            wg.wait_stream(self._main)
+            if not defer_identity:
+                enqueue_identity()
         if side is not None:
             main = self._main
             side.wait_stream(main)
@@ -727,6 +738,8 @@ class Engine:
                                                      waits=None if inputs_ready is None else inputs_ready[1:3])[4]
             self._pose_decoder(ws, pf4)
         ws.dfeats, ws.pf4 = dfeats, pf4
+        if defer_identity:
+            enqueue_identity()
         # view synthesis + loss ------------------------------------------------------------------
         if inputs_ready is not None:
             self._main.wait_event(inputs_ready[3])

@@ -20,6 +20,11 @@ for ctr in FETCH_SIZE WRITE_SIZE; do
     python tools/pmc_summary.py $db conv > $OUT/${TAG}_pmc_$ctr.txt 2>&1
     eval "DB_$ctr=$db"
 done
+# MFMA-busy evidence (north_star: "rocprof ... MFMA-busy against gfx950 peak"): two more counter passes of the same build
+rm -rf /tmp/pmc_sqA /tmp/pmc_sqB
+(cd /tmp && CLSLAM_SIDE_STREAM=0 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES -d /tmp/pmc_sqA -o run -- python $OLDPWD/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-also > /tmp/pmc_sqA.log 2>&1)
+(cd /tmp && CLSLAM_SIDE_STREAM=0 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES -d /tmp/pmc_sqB -o run -- python $OLDPWD/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-also > /tmp/pmc_sqB.log 2>&1)
+python tools/pmc_mfma_busy.py $(ls /tmp/pmc_sqA/*/*.db /tmp/pmc_sqA/*.db 2>/dev/null | head -1) $(ls /tmp/pmc_sqB/*/*.db /tmp/pmc_sqB/*.db 2>/dev/null | head -1) conv > $OUT/${TAG}_pmc_mfma_busy.txt 2>&1
 # L2-miss traffic per launch of every conv kernel, keyed by kernel name: bench.py's roofline.traffic reads THIS file
 python tools/pmc_traffic.py $DB_FETCH_SIZE $DB_WRITE_SIZE $OUT/${TAG}_pmc_traffic.json > $OUT/${TAG}_pmc_traffic.log 2>&1
 cp $OUT/${TAG}_pmc_traffic.json profiles/pmc_traffic.json
@@ -40,6 +45,8 @@ brief() { python -c "import json,sys; d=json.loads(sys.stdin.read().strip().spli
   for r in 0 2 32; do echo "== 192x640 replay $r"; python bench.py --replay $r --steps 20 --warmup 5 --no-cpu-baseline | brief; done
   echo "== 192x640 replay 4, uniform-random images"; python bench.py --random-images --steps 20 --warmup 5 --no-cpu-baseline --no-also | brief
   echo "== 384x1280 replay 8"; python bench.py --height 384 --width 1280 --replay 8 --steps 10 --warmup 3 --no-cpu-baseline | brief
+  echo "== 384x1280 replay 8 + loop-closure encoder forward in every frame (BASELINE config 5 on one GPU, ONE number)"; python bench.py --height 384 --width 1280 --replay 8 --lcd --steps 10 --warmup 3 --no-cpu-baseline | brief
+  echo "== 192x640 replay 4, opt-in host-output path"; python bench.py --host-outputs --steps 50 --warmup 5 --no-cpu-baseline --no-also | brief
 } > $OUT/${TAG}_other_configs.txt 2>&1
 BENCH_WGRAD=1 python tools/bench_conv.py 5 30,31,32,33 > $OUT/${TAG}_conv_microbench.txt 2>&1
 BENCH_WGRAD=0 python tools/bench_conv.py 1 30,31,32,33 > $OUT/${TAG}_conv_microbench_b1.txt 2>&1
@@ -49,4 +56,8 @@ BENCH_DGRAD=1 BENCH_WGRAD=0 python tools/bench_conv.py 5 20,21,22,26,30,31,32,33
 python tools/bench_gpu_bound.py 2>&1 | grep 'K=' > $OUT/${TAG}_gpu_bound.txt
 python tools/bench_memo.py 2>&1 | grep -v amdgpu > $OUT/${TAG}_descriptor_memo.txt
 bash tools/dp2_gloo.sh > $OUT/${TAG}_dp2_gloo.txt 2>&1
+# the measured numbers the parity tests print (trajectory envelope through steps=5, backward ladder, configs 4 / 5 at full workload)
+python -m pytest tests/test_trajectory.py -q -m gpu -s 2>&1 | grep "^\[hip\|passed\|failed" > $OUT/${TAG}_trajectory.txt
+python -m pytest tests/test_backward_parity.py -q -m gpu -s 2>&1 | grep "hip \|    \|passed\|failed" > $OUT/${TAG}_backward_parity.txt
+python -m pytest tests/test_configs_4_5.py -q -s 2>&1 | grep "^\[config\|passed\|failed" > $OUT/${TAG}_configs_4_5.txt
 echo done
