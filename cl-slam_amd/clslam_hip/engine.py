@@ -162,6 +162,8 @@ class Engine:
         self._train_done = None       # event: the last detached training step (incl. its optimizer step) has completed
         self._caller = None           # the caller's stream while a detached call is being enqueued
         self.inputs_released = None
+        self._prealloc = None         # output planes allocated by the caller's stream for the call's last forward (prealloc_outputs)
+        self._prealloc_armed = False
         self.side_stream = pool.get('side')
         self.wg_stream = pool.get('wg')
         # split-K scratch of the small-M 3x3 convs: one zero-filled buffer per stream convs are launched on
@@ -281,6 +283,16 @@ class Engine:
         self.wait_training()
         return self._v
 
+    def prealloc_outputs(self, B: int) -> None:
+        """Called on the CALLER's stream right before a detached training call: the output planes of the call's last forward,
+        allocated from the caller's pool.  The engine's stream writes them (it is ordered behind the caller at
+        begin_detached()), the caller reads them behind `inputs_released` -- after which nothing on the engine's streams
+        touches them any more (backward(): the loss backward's three launches are the last readers) -- and frees them."""
+        H, W = self.H, self.W
+        E = lambda *s: torch.empty(*s, device=self.device)  # noqa: E731
+        self._prealloc = (B, ([E(B, H >> s, W >> s) for s in range(4)], E(2 * B, 12), E(2, B, 4, 4), E(4, B, H, W),
+                              E(4, 2, B, 3, H, W), E(18)))
+
     def detached_ok(self) -> bool:
         """A training adapt() may run on the engine's own stream (see __init__)."""
         return (self.detached_training and self.main_stream is not None and self.device.type == 'cuda'
@@ -301,6 +313,7 @@ class Engine:
         """The caller's stream continues behind `released` (backward(): the last read of the caller's minibatch, ~0.1 ms into
         the backward); everything that touches trainable state or the workspace waits through wait_training()."""
         self._caller = None
+        self._prealloc, self._prealloc_armed = None, False
         ev = torch.cuda.Event()
         ev.record(self.main_stream)
         self._train_done = ev
@@ -631,15 +644,18 @@ class Engine:
         if self.fresh_outputs:
             # the reference returns fresh tensors from every call: the output planes are (cheap, cached)
             # new allocations that the kernels write directly -- no copies
-            E = lambda *s: torch.empty(*s, device=self.device)  # noqa: E731
-            ws.disp = [E(B, H >> s, W >> s) for s in range(4)]
-            ws.pose, ws.T = E(2 * B, 12), E(2, B, 4, 4)
-            ws.depth, ws.warped, ws.losses = E(4, B, H, W), E(4, 2, B, 3, H, W), E(18)
-            if self._caller is not None:
-                # detached training step: these blocks come from the engine stream's pool and are handed to the caller, who
-                # reads them on ITS stream -- the allocator must not recycle them under a read still queued there
-                for t_ in (*ws.disp, ws.pose, ws.T, ws.depth, ws.warped, ws.losses):
-                    t_.record_stream(self._caller)
+            pre = self._prealloc if self._prealloc_armed else None
+            if pre is not None and pre[0] == B:
+                self._prealloc = None
+                # detached step: allocated by the caller's stream (prealloc_outputs) -- the blocks belong to the pool of the
+                # stream that will read and free them, so no record_stream bookkeeping is needed (it cost ~0.1 ms per step at
+                # B = 1: an event per block and free, polled by every later allocation)
+                ws.disp, ws.pose, ws.T, ws.depth, ws.warped, ws.losses = pre[1]
+            else:
+                E = lambda *s: torch.empty(*s, device=self.device)  # noqa: E731
+                ws.disp = [E(B, H >> s, W >> s) for s in range(4)]
+                ws.pose, ws.T = E(2 * B, 12), E(2, B, 4, 4)
+                ws.depth, ws.warped, ws.losses = E(4, B, H, W), E(4, 2, B, 3, H, W), E(18)
         def identity_and_noise() -> bool:
             """Identity reprojection maps (dpp.py:1047-1052) and the tie-break noise depend on the inputs only."""
             if not reuse:

@@ -355,10 +355,13 @@ class DepthPosePrediction:
             cur = em = released = None
             if eng.detached_ok():
                 cur, em = eng.begin_detached()
+                if em is not None:      # still on the caller's stream: the output planes of the call's last forward
+                    eng.prealloc_outputs(training_data['rgb_aug', 0, 0].shape[0])
             failed = True
             try:
                 with (torch.cuda.stream(em) if em is not None else _null_context()):
                     for it in range(steps):
+                        eng._prealloc_armed = it == steps - 1      # the planes this call hands out: the caller's pool (below)
                         # steps 2..S see the same minibatch through the same frozen, eval-mode encoders (dpp.py:308-313):
                         # their features and the identity-reprojection maps are kept, only the decoders re-run
                         if eng.graph_preferred(training_data['rgb_aug', 0, 0].shape[0]):

@@ -91,17 +91,19 @@ def _run(backend, H, W, B, seed, capsys):
         p = make_predictor(H, W, B)
         perturb(p.models, k)
         hips.append(_hip_trajectory(p, batch, noises))
-    # the same five steps as ONE adapt(steps=5) call (frozen-feature reuse inside the call, one noise field for all five
-    # steps): the final forward is what the reference's shipped configuration returns -- bitwise the step-by-step run's
-    q = make_predictor(H, W, B)
-    q.set_tie_break_noise(noises[0])
-    out5, l5 = q.adapt(None, {k: v.clone() for k, v in batch.items()}, steps=STEPS)
-    r = make_predictor(H, W, B)
-    r.set_tie_break_noise(noises[0])
-    for _ in range(STEPS):
-        out1, l1 = r.adapt(None, {k: v.clone() for k, v in batch.items()}, steps=1)
-    assert torch.equal(out5['disp', 0], out1['disp', 0]) and torch.equal(l5['loss'], l1['loss'])
-    assert torch.equal(q.engine.w, r.engine.w)
+    if backend == 'hip':
+        # the same five steps as ONE adapt(steps=5) call (frozen-feature reuse inside the call, one noise field for all five
+        # steps): the final forward is what the reference's shipped configuration returns -- bitwise the step-by-step run's
+        # (tests/test_frozen_reuse.py holds the same on the emulator at a smaller size)
+        q = make_predictor(H, W, B)
+        q.set_tie_break_noise(noises[0])
+        out5, l5 = q.adapt(None, {k: v.clone() for k, v in batch.items()}, steps=STEPS)
+        r = make_predictor(H, W, B)
+        r.set_tie_break_noise(noises[0])
+        for _ in range(STEPS):
+            out1, l1 = r.adapt(None, {k: v.clone() for k, v in batch.items()}, steps=1)
+        assert torch.equal(out5['disp', 0], out1['disp', 0]) and torch.equal(l5['loss'], l1['loss'])
+        assert torch.equal(q.engine.w, r.engine.w)
     lines, bad = [], []
     for it in range(STEPS):
         dhs = [_dist(h[it], exact[it]) for h in hips]
