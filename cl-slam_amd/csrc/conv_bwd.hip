@@ -164,11 +164,22 @@ __global__ __launch_bounds__(256) void fold_act_grad_kernel(const float* __restr
         bacc.x += acc.x; bacc.y += acc.y; bacc.z += acc.z; bacc.w += acc.w;
     }
     if (bias_partial) {
-        bred[threadIdx.x] = bacc;
+        // threads of one channel quad sit C4 lanes apart (C4 | 64): shuffle inside the wave, the four waves meet in LDS.  (The
+        // serial walk over 256 / C4 LDS entries this replaces was 64 dependent reads per block at C = 16 -- on the
+        // data-gradient chain, ten times per step.)
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        float4 v = bacc;
+        for (int m = C4; m < 64; m <<= 1) {
+            v.x += wave_shfl_xor(v.x, m); v.y += wave_shfl_xor(v.y, m);
+            v.z += wave_shfl_xor(v.z, m); v.w += wave_shfl_xor(v.w, m);
+        }
+        if (lane < C4) bred[wave * 64 + lane] = v;
         __syncthreads();
         if ((int)threadIdx.x < C4) {
-            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int k = threadIdx.x; k < 256; k += C4) { const float4 v = bred[k]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+            const float4 a0 = bred[threadIdx.x], a1 = bred[64 + threadIdx.x], a2 = bred[128 + threadIdx.x], a3 = bred[192 + threadIdx.x];
+            float4 t;
+            t.x = (a0.x + a1.x) + (a2.x + a3.x); t.y = (a0.y + a1.y) + (a2.y + a3.y);
+            t.z = (a0.z + a1.z) + (a2.z + a3.z); t.w = (a0.w + a1.w) + (a2.w + a3.w);
             *reinterpret_cast<float4*>(bias_partial + (size_t)blockIdx.x * C + threadIdx.x * 4) = t;
         }
     }
@@ -544,7 +555,7 @@ extern "C" int clslam_fold_act_grad(const float* dxp, const float* yout, float* 
     CLSLAM_REQUIRE(!pool || (h % 2 == 0 && w % 2 == 0), "fold_act_grad: pooling needs even dims");
     const size_t total = (size_t)batch * (pool ? h / 2 : h) * (pool ? w / 2 : w) * (ch / 4);
     if (total == 0) return CLSLAM_OK;
-    CLSLAM_REQUIRE(!bias_partial || (256 % (ch / 4) == 0), "fold_act_grad: fused bias sums need ch/4 to divide 256");
+    CLSLAM_REQUIRE(!bias_partial || (64 % (ch / 4) == 0), "fold_act_grad: fused bias sums need ch/4 to divide 64");
     CLSLAM_REQUIRE(total < ((size_t)1 << 31) - 256 * 4096, "fold_act_grad: tensor too large for 32-bit indexing");
     const int blocks = clslam_fold_blocks(batch, h, w, ch, pool);
     hipLaunchKernelGGL(fold_act_grad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dxp, yout, dz, bias_partial, batch,
