@@ -14,6 +14,7 @@ H, W = 192, 640
 for K in ([int(a) for a in sys.argv[1:]] or (0, 2, 4)):
     B = K + 1
     p = bench.build_predictor(H, W, B)
+    p.engine.detached_training = False    # the whole step on the caller's stream: the spin and the two events below live there
     batch = {k: v.cuda() for k, v in synth.make_batch(B, H, W, seed=0).items()}
     for _ in range(60):          # warm clocks: the spin below and a fresh predictor both let them drop
         p.adapt(None, batch, steps=1)
