@@ -160,7 +160,7 @@ def _run(backend, H, W, B, seed, capsys):
 
 @pytest.mark.parametrize('backend', BACKENDS)
 def test_five_step_trajectory_stays_inside_the_fp32_envelope(backend, capsys):
-    _run(backend, 64, 128, 3, 31, capsys)
+    _run(backend, 64, 128, 3 if backend == 'hip' else 2, 31, capsys)      # (the emulator: two triplets keep the CPU suite short)
 
 
 @pytest.mark.gpu
