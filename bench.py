@@ -166,7 +166,7 @@ def main():
     from clslam_hip import _lib, ops, synth
     build_id = _lib.build_id()
     torch.manual_seed(1 + rank)          # the tie-break noise is drawn on the device: same trajectory every run
-    p = build_predictor(H, W, B if N == 1 else Bl, host_outputs=args.host_outputs)
+    p = build_predictor(H, W, B if N == 1 else max(Bl, 1), host_outputs=args.host_outputs)   # (a rank may hold no sample: --total-replay K < N-1)
     if N > 1:
         p.enable_data_parallel(B, offset)
     full = synth.make_batch(B, H, W, seed=0)

@@ -343,6 +343,11 @@ class DepthPosePrediction:
         if training_data is not None:
             self._set_adapt(freeze_encoder=True)
             self.engine.pack_if_needed()
+            if self._dp is not None and training_data['rgb_aug', 0, 0].shape[0] == 0:
+                # data-parallel rank WITHOUT samples (the replay buffer is still filling up: the global minibatch is smaller
+                # than the number of ranks, slam/replay_buffer.py): it takes part in every collective with zeros and applies
+                # the same optimizer step, so the replicas stay identical
+                return self._empty_shard_steps(steps)
             # The step runs on the ENGINE's stream (Engine.main_stream): forward, backward and the optimizer step go out
             # behind each other there, and the caller's stream is only ordered behind the last forward + the first three
             # launches of its backward (the last reads of the caller's minibatch and of the output planes: ~0.1 ms) -- the
@@ -404,6 +409,40 @@ class DepthPosePrediction:
             self.engine.pack_if_needed()
             outputs_eval, losses = self._process_batch(online_data, loss_weights, train=False)
         return outputs_eval, losses
+
+    def _empty_shard_steps(self, steps: int):
+        """adapt() of a data-parallel rank whose shard is empty: the same sequence of collectives as a rank with samples
+        (18 loss scalars, then the gradient arena -- in the engine's buckets, or whole on the hipGraph path), contributing
+        zeros; the NaN check on the all-reduced loss and the guarded Adam step like everywhere else."""
+        eng, dist, group = self.engine, self._dp['dist'], self._dp['group']
+        eng.wait_training()
+        bucketed = eng.grad_buckets > 1 and not eng.graph_preferred(1)
+        for _ in range(steps):
+            losses = torch.zeros(18, device=self.device)
+            dist.all_reduce(losses, group=group)
+            self._losses_dev = losses
+            eng._g.zero_()
+            if bucketed:
+                for _name, lo, hi in eng.bucket_ranges():
+                    self._allreduce(eng._g[lo:hi])
+            else:
+                dist.all_reduce(eng._g, group=group)
+            self.optimizer.loss_guard = losses[17:18]
+            self.optimizer.step()
+            self.optimizer.loss_guard = None
+            self._raise_on_nan(eng.losses_dict(losses.detach().cpu()), undo_step=True)
+        H, W, dev = self.height, self.width, self.device
+        E = lambda *shape: torch.empty(*shape, device=dev)  # noqa: E731
+        outputs: Dict[Any, Tensor] = {}
+        for s in (3, 2, 1, 0):
+            outputs['disp', s] = E(0, 1, H >> s, W >> s)
+        for f in (-1, 1):
+            outputs['axis_angle', 0, f], outputs['translation', 0, f], outputs['cam_T_cam', 0, f] = E(0, 1, 3), E(0, 1, 3), E(0, 4, 4)
+        for s in range(4):
+            outputs['depth', s] = E(0, 1, H, W)
+            for f in (-1, 1):
+                outputs['rgb', f, s] = E(0, 3, H, W)
+        return outputs, eng.losses_dict(losses)
 
     # ============================================================
     # Predict functions

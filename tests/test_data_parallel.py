@@ -34,7 +34,7 @@ def _worker(rank, world, port, counts, out_dir, steps, streamk, backend='emu'):
         use_backend('emu')
         dist.init_process_group('gloo', rank=rank, world_size=world)
     off = sum(counts[:rank])
-    p = make_predictor(H, W, counts[rank])
+    p = make_predictor(H, W, max(counts[rank], 1))
     p.enable_data_parallel(B, off)
     full = synth.make_batch(B, H, W, seed=4)
     noise = synth.make_noise(B, H, W, seed=8)
@@ -113,6 +113,32 @@ def test_two_ranks_equal_single_rank(tmp_path, monkeypatch, steps, streamk):
         assert torch.equal(r['full_depth'], r0['full_depth'])
         assert torch.allclose(r['full_depth'], out['depth', 0], rtol=1e-5, atol=0)
         assert torch.allclose(r['full_T'], out['cam_T_cam', 0, -1], atol=1e-6)
+
+
+@pytest.mark.timeout(900)
+def test_a_rank_without_samples_takes_part_with_zeros(tmp_path):
+    """While the replay buffer is still filling up the global minibatch is smaller than the number of ranks (slam.py:150-160:
+    `training_data` is the online sample alone at first): a rank whose shard is EMPTY still posts every collective (zeros) and
+    applies the same optimizer step.  Shards 3 + 0 over two steps: both ranks end bit-identical, and rank 0 -- which holds the
+    whole minibatch -- is bitwise the single process (x + 0 == x)."""
+    sys.path.insert(0, str(ROOT / 'tests'))
+    from clslam_hip import synth
+    from emu_util import use_backend
+    from predictor_util import make_predictor
+    use_backend('emu')
+    steps = 2
+    p = make_predictor(H, W, B)
+    p.set_tie_break_noise(synth.make_noise(B, H, W, seed=8))
+    full = synth.make_batch(B, H, W, seed=4)
+    out, losses = p.adapt(None, {k: v.clone() for k, v in full.items()}, steps=steps)
+    port = 29500 + (os.getpid() % 2000) + 7
+    mp.start_processes(_worker, args=(2, port, [3, 0], str(tmp_path), steps, True), nprocs=2, join=True, start_method='spawn')
+    r0, r1 = torch.load(tmp_path / 'rank0.pt'), torch.load(tmp_path / 'rank1.pt')
+    assert torch.equal(r0['g'], r1['g']) and torch.equal(r0['w'], r1['w']) and r0['in_sync'] and r1['in_sync']
+    assert torch.equal(r0['w'], p.engine.w) and torch.equal(r0['g'], p.engine.g)
+    for k, v in losses.items():
+        assert float(r0['loss'][k]) == float(v) == float(r1['loss'][k]), k
+    assert r1['T'].shape == (0, 4, 4) and torch.equal(r1['full_depth'], out['depth', 0]) and torch.equal(r0['full_depth'], out['depth', 0])
 
 
 @pytest.mark.gpu
