@@ -152,9 +152,10 @@ class Engine:
         # 3.33 ms per step measured with three predictors alive)
         pool = _device_streams(device)
         # The engine's own in-order compute stream.  A training adapt() runs there: forward, backward and the optimizer step
-        # are enqueued behind each other, the CALLER's stream is only ordered behind the FORWARD (an event), so what the
-        # reference's callers do next -- outputs['cam_T_cam', 0, 1][0].cpu(), losses[k].cpu() (slam.py:181-188) -- waits for
-        # the forward alone while backward + Adam keep the GPU busy; whatever touches trainable state or the workspace
+        # are enqueued behind each other, the CALLER's stream is only ordered behind the forward and the first three launches
+        # of the backward (`inputs_released`: the last reads of the caller's minibatch and of the output planes), so what the
+        # reference's callers do next -- outputs['cam_T_cam', 0, 1][0].cpu(), losses[k].cpu() (slam.py:181-188) -- returns
+        # while the rest of the backward + Adam keep the GPU busy; whatever touches trainable state or the workspace
         # afterwards is ordered behind the step by wait_training().  CLSLAM_DETACHED_TRAINING=0: everything on the caller's
         # stream like rounds 1-3 (bitwise the same results, tests/test_detached_training.py).
         self.main_stream = pool.get('main')
