@@ -28,7 +28,7 @@ class ConvDesc(C.Structure):
                 ('out_h', i32), ('out_w', i32), ('ch_out', i32),
                 ('ksize', i32), ('stride', i32), ('pad', i32), ('pad_mode', i32), ('upsample_a', i32),
                 ('act', i32), ('config', i32), ('actgrad_src', fptr), ('actgrad_kind', i32),
-                ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t)]
+                ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t), ('weight_wino', fptr)]
 
 
 class TransposeItem(C.Structure):
@@ -53,6 +53,7 @@ _SIGNATURES = {
     'clslam_is_device_build': [],
     'clslam_conv2d': [C.POINTER(ConvDesc), C.c_void_p],
     'clslam_conv2d_pick_config': [C.POINTER(ConvDesc)],
+    'clslam_wino_weight_transform': [fptr, fptr, i32, i32, C.c_void_p],
     'clslam_weight_transpose': [fptr, fptr, i32, i32, i32, i32, C.c_void_p],
     'clslam_weight_transpose_multi': [C.POINTER(TransposeItem), i32, C.c_void_p],
     'clslam_fold_blocks': [i32, i32, i32, i32, i32],
@@ -134,6 +135,7 @@ _SIGNATURES = {
                                 fptr, C.c_void_p],
 }
 _RESTYPES = {'clslam_last_error': C.c_char_p, 'clslam_build_id': C.c_char_p}
+_SIZE_FNS = {'clslam_wino_weight_size': [i32, i32]}      # return size_t
 
 
 class ClslamError(RuntimeError):
@@ -151,6 +153,9 @@ class Library:
         for name, rt in _RESTYPES.items():
             fn = getattr(self.cdll, name)
             fn.restype, fn.argtypes = rt, []
+        for name, argtypes in _SIZE_FNS.items():
+            fn = getattr(self.cdll, name)
+            fn.restype, fn.argtypes = C.c_size_t, argtypes
         for name, argtypes in _SIGNATURES.items():
             fn = getattr(self.cdll, name)  # AttributeError if the symbol is not exported
             fn.argtypes = argtypes
@@ -187,7 +192,7 @@ def install_library_for_tests(path) -> Library:
 
 
 def exported_symbols():
-    return list(_RESTYPES) + list(_SIGNATURES)
+    return list(_RESTYPES) + list(_SIZE_FNS) + list(_SIGNATURES)
 
 
 def build_id() -> str:

@@ -20,6 +20,9 @@ OBJ_DIR = CSRC / 'build'
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-DCLSLAM_DEVICE_BUILD=1',
          '-I', str(CSRC / 'include'), '-Wno-unused-result'] + os.environ.get('CLSLAM_HIPCC_EXTRA', '').split()
+# per-source flags.  conv_wino.hip names a0-a255 in its MFMA statements (intrin.h, AccFile): the compiler must not park its own
+# spills in the accumulator file
+FILE_FLAGS = {'conv_wino': ['-mllvm', '-amdgpu-spill-vgpr-to-agpr=0']}
 
 
 def source_id() -> str:
@@ -32,6 +35,9 @@ def source_id() -> str:
     for f in files:
         h.update(f.name.encode())
         h.update(f.read_bytes())
+    # the flags are part of the identity: a diagnostic build (CLSLAM_HIPCC_EXTRA=-DCLSLAM_EXACT_DIV, probe builds of conv_wino.hip)
+    # must not pass for the production library
+    h.update(repr((FLAGS, sorted(FILE_FLAGS.items()))).encode().replace(str(CSRC).encode(), b'<csrc>'))
     return h.hexdigest()[:16]
 
 
@@ -73,7 +79,7 @@ def build(force: bool = False, verbose: bool = True) -> Path:
     def cc(job):
         s, o = job
         extra = [f'-DCLSLAM_BUILD_ID="clslam-build-id:{sid}"'] if s.stem == 'capi' else []
-        cmd = [HIPCC, *FLAGS, *extra, '-c', str(s), '-o', str(o)]
+        cmd = [HIPCC, *FLAGS, *FILE_FLAGS.get(s.stem, []), *extra, '-c', str(s), '-o', str(o)]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f'hipcc failed for {s.name}:\n{r.stderr[-4000:]}')

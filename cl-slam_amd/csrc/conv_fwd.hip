@@ -228,7 +228,9 @@ static int launch_conv(ConvK k, hipStream_t stream) {
 }  // namespace clslam
 
 namespace clslam { int conv3x3_patch_dispatch(const clslam_conv_desc* d, int cfg, hipStream_t stream);
-                   int conv3x3_sk_dispatch(const clslam_conv_desc* d, int cfg, hipStream_t stream); }
+                   int conv3x3_sk_dispatch(const clslam_conv_desc* d, int cfg, hipStream_t stream);
+                   int conv3x3_wino_dispatch(const clslam_conv_desc* d, hipStream_t stream);
+                   int conv3x3_wino_supported(const clslam_conv_desc* d); }
 
 using namespace clslam;
 
@@ -246,6 +248,9 @@ extern "C" int clslam_conv2d_pick_config(const clslam_conv_desc* d) {
     const int Cin = d->ch_a + d->ch_b;
     const int M = d->batch * d->out_h * d->out_w;
     const bool bk32 = (Cin % 32 == 0) && (d->ch_b == 0 || d->ch_a % 32 == 0);
+    // Winograd F(2x2,3x3) (conv_wino.hip, config 40) wherever the caller supplied the transformed filter: 2.25x fewer MFMAs
+    if (d->config != -2 && d->workspace != nullptr && conv3x3_wino_supported(d) && Cin >= 64 && d->ch_out >= 64 && !getenv("CLSLAM_NO_WINOGRAD"))
+        return 40;
     // 3x3 stride-1: the LDS-patch kernel (conv_patch.hip).  Measured on MI355X (tools/bench_conv.py,
     // B=5 @192x640): 128 px x 16 ch tiles reach 80-104 TFLOP/s on the >= 48x160 layers, 64 px x 16 ch
     // tiles 65-95 TFLOP/s on the smaller ones, 64-px row-major runs 46-70 TFLOP/s on the 6x20 layers
@@ -359,6 +364,7 @@ extern "C" int clslam_conv2d(const clslam_conv_desc* d, void* stream_) {
     int cfg = d->config;
     const bool bk32 = (Cin % 32 == 0) && (d->ch_b == 0 || d->ch_a % 32 == 0);
     if (cfg < 0) cfg = clslam_conv2d_pick_config(d);
+    if (cfg == 40) return conv3x3_wino_dispatch(d, stream);
     if (cfg >= 30) {
         const int rc = conv3x3_sk_dispatch(d, cfg, stream);
         if (rc == CLSLAM_OK || d->config >= 0) return rc;

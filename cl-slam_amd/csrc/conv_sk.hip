@@ -426,7 +426,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void conv3x3_sk_kernel(SkK p) {
 }
 
 // Number of CUs of the current device (the persistent grid is sized from it, not from a constant).
-static int sk_device_cus() {
+int sk_device_cus() {
 #if CLSLAM_DEVICE_BUILD
     static thread_local int cached_dev = -1, cached_cus = 0;
     int dev = 0;
@@ -445,7 +445,7 @@ static int sk_device_cus() {
 // Per-workspace launch epoch: consecutive launches on a stream publish different flag values (never 0).  Inside a
 // hipGraph capture the argument is frozen, i.e. every replay uses the same value -- the consumer's reset to 0 keeps
 // that case working exactly like a 0/1 flag.
-static unsigned sk_next_epoch(const void* workspace) {
+unsigned sk_next_epoch(const void* workspace) {
     static std::mutex mu;
     static std::unordered_map<const void*, unsigned> epochs;
     std::lock_guard<std::mutex> lock(mu);

@@ -80,10 +80,20 @@ typedef struct clslam_conv_desc {
      * which workgroup finishes last: partial tiles are summed in split order.                       */
     void* workspace;
     size_t workspace_bytes;
+    /* Optional (ABI version >= 101): the same filter pre-transformed for the Winograd F(2x2,3x3) kernel by
+     * clslam_wino_weight_transform (3x3, stride 1, zero padding, one source; needs `workspace`).  NULL: the direct kernels.
+     * Frozen weights (the two ResNet encoders) are transformed once per load; `weight` must still be set.              */
+    const float* weight_wino;
 } clslam_conv_desc;
 int clslam_conv2d(const clslam_conv_desc* desc, void* stream);
 /* the tile configuration clslam_conv2d uses for desc->config < 0 (profiling / reporting) */
 int clslam_conv2d_pick_config(const clslam_conv_desc* desc);
+/* U = G g G^T of Winograd F(2x2,3x3) for a 3x3 filter w [ch_out][9][ch_in] (ch_in a multiple of 16), formed in double and
+ * rounded once, in the layout the kernel stages through LDS: clslam_wino_weight_size(ch_out, ch_in) floats
+ * ([ceil(ch_out/64)][ch_in/8][16 positions][64][8], zero beyond ch_out).  Replaces nothing in the reference: cuDNN does the
+ * same transformation inside its own Winograd convolution (networks/resnet_encoder.py:118-125 on the GPU).            */
+size_t clslam_wino_weight_size(int ch_out, int ch_in);
+int clslam_wino_weight_transform(const float* w, float* u, int ch_out, int ch_in, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Backward of the trainable convolutions -- replaces autograd's convolution_backward,

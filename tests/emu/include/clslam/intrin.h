@@ -84,8 +84,16 @@ inline unsigned coherent_load_u32(const unsigned* p) { return __atomic_load_n(p,
 inline void spin_pause() { ::emu_yield_os(); }   // the producer block runs on another host thread
 // LDS-DMA emulated as an immediate copy: lane l's 16 bytes land at lds_wave_base + l * 16
 inline void lds_dma16(const float* gsrc, float* lds_wave_base) { memcpy(lds_wave_base + lane_id() * 4, gsrc, 16); }
+inline unsigned lds_addr(const float*) { return 0u; }
+inline void lds_dma16_at(const float* gsrc, float* lds_array, unsigned, unsigned float_offset) { memcpy(lds_array + float_offset + lane_id() * 4, gsrc, 16); }
+inline void lds_dma16_x4(const float* gsrc, float* lds_array, unsigned, unsigned float_offset) { for (int i = 0; i < 4; ++i) memcpy(lds_array + float_offset + i * 256 + lane_id() * 4, gsrc + i * 256, 16); }
 inline void dma_wait_all() {}
+inline void dma_wait_keep8() {}
 inline void sched_fence() {}
+inline int launder(int v) { return v; }
+inline void pin4(float4&, float4&, float4&, float4&) {}
+inline void pin2(float4&, float4&) {}
+inline void pin1(float4&) {}
 inline void uncounted_flag_store(unsigned* p, unsigned v) { __atomic_store_n(p, v, __ATOMIC_SEQ_CST); }
 inline void uncounted_store4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 inline void mfma_results_settle() {}
@@ -94,6 +102,10 @@ inline void coherent_store4(float* p, f32x4 v) { memcpy(p, &v, 16); __atomic_thr
 inline void coherent_load4x4(const float* p, f32x4& a, f32x4& b, f32x4& c, f32x4& d) {
     __atomic_thread_fence(__ATOMIC_SEQ_CST);
     memcpy(&a, p, 16); memcpy(&b, p + 256, 16); memcpy(&c, p + 512, 16); memcpy(&d, p + 768, 16);
+}
+inline void coherent_load4x8(const float* p, f32x4 (&v)[8]) {
+    __atomic_thread_fence(__ATOMIC_SEQ_CST);
+    for (int i = 0; i < 8; ++i) memcpy(&v[i], p + 256 * i, 16);
 }
 inline void coherent_load4x2(const float* p, f32x4& a, f32x4& b) {
     __atomic_thread_fence(__ATOMIC_SEQ_CST);
@@ -110,6 +122,17 @@ inline void coherent_load4x2_x4(const float* p0, const float* p1, const float* p
     coherent_load4x2(p2, c[0], c[1]); coherent_load4x2(p3, d[0], d[1]);
 }
 inline void wg_barrier_keep_dma() { emu_sync_block(); }
+
+// pinned accumulators of conv_wino.hip: the emulator keeps the sixteen 32x32 tiles in the struct
+struct AccFile { f32x16 t[16]; };
+template <int P, bool GUARD>
+inline void acc_mfma(AccFile& f, float a, float b) { f.t[P] = mfma_32x32x2(a, b, f.t[P]); }
+template <int P>
+inline void acc_zero(AccFile& f) { for (int r = 0; r < 16; ++r) f.t[P][r] = 0.f; }
+inline void acc_settle() {}
+template <int P>
+inline f32x16 acc_read(AccFile& f) { return f.t[P]; }
+
 
 inline float wave_shfl_xor(float v, int mask) {
     const int l = lane_id();

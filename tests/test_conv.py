@@ -232,3 +232,50 @@ def test_conv_profile_hook_times_every_launch(backend):
         assert all(1e-7 < g[3] < 1e-2 for g in got), got
     ops.conv2d(x, w, out, ksize=3)          # disarmed again: plain launches
     ops.profile_begin(); assert ops.profile_end() == []
+
+
+# B, H, W, Cin, Cout, pad, act, resid, groups
+WINO_CASES = [
+    (1, 16, 16, 16, 64, 1, 1, True, 1),      # one 8x8-tile region, two stages, one workgroup
+    (2, 12, 20, 32, 64, 1, 1, True, 5),      # 6x10 regions, ranges cut inside a region (hand-off), residual + ReLU
+    (5, 6, 20, 32, 128, 1, 0, False, 7),     # two whole 6x20 images per region (last one half empty), two channel tiles
+    (1, 24, 40, 16, 48, 1, 1, False, 3),     # ragged Cout (48 of a 64 tile), several regions per image
+    (2, 7, 11, 32, 64, 1, 1, True, 4),       # odd image: half-valid tiles at the right / bottom edge
+    (1, 14, 44, 32, 64, 2, 0, False, 6),     # dgrad-like padded domain (pad = 2: output 16x46)
+    (3, 6, 20, 64, 64, 1, 1, True, 16),      # one region shared by many groups (B = 1 regime)
+    (1, 48, 32, 16, 64, 1, 1, False, 2),     # tall image, 8x8 regions
+]
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+@pytest.mark.parametrize('case', WINO_CASES)
+def test_conv2d_winograd(backend, case, monkeypatch):
+    """conv_wino.hip (config 40): F(2x2,3x3) on the 32x32x2 MFMA with the input transform in registers.  Same result as torch
+    for every cut of the unit stream, bitwise repeatable, hand-off flags back at zero; fp32 Winograd carries about twice the
+    rounding error of the direct form (3.6e-7...6.9e-7 of max|y| at 64...512 channels), far inside the 2e-5 of this file."""
+    dev = use_backend(backend)
+    B, H, W, Cin, Cout, pad, act, resid, groups = case
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(B, H, W, Cin, generator=g)
+    w = torch.randn(Cout, 9, Cin, generator=g) * 0.05
+    scale, shift = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.1
+    Ho, Wo = H + 2 * pad - 2, W + 2 * pad - 2
+    res = torch.randn(B, Ho, Wo, Cout, generator=g) if resid else None
+    ref = _ref_conv(x, w, scale=scale, shift=shift, residual=res, ksize=3, stride=1, pad=pad, act=act)
+    t = lambda v: None if v is None else v.to(dev)   # noqa: E731
+    ws = torch.zeros(20 << 20, dtype=torch.uint8, device=dev)
+    monkeypatch.setattr(ops, '_CONV_WORKSPACES', {})
+    u = ops.wino_weight_transform(t(w))
+    outs = []
+    for grp in (groups, groups, 1):
+        monkeypatch.setenv('CLSLAM_SK_GROUPS', str(grp))
+        out = torch.full((B, Ho, Wo, Cout), float('nan'), device=dev)
+        ops.conv2d(t(x), t(w), out, scale=t(scale), shift=t(shift), residual=t(res), ksize=3, pad=pad, act=act, config=40,
+                   workspace=ws, weight_wino=u)
+        outs.append(out.cpu())
+    assert rel_err(outs[0], ref) < 2e-5, rel_err(outs[0], ref)
+    assert torch.equal(outs[0], outs[1])
+    assert rel_err(outs[0], outs[2]) < 1e-5
+    assert int(ws[:65536].view(torch.int32).abs().sum()) == 0
+    with pytest.raises(Exception, match='weight_wino'):
+        ops.conv2d(t(x), t(w), out, ksize=3, pad=pad, config=40, workspace=ws)

@@ -83,11 +83,16 @@ for name, bm, Hi, Wi, Ca, Cb, Cout, k, stride, refl, ups, *rest in LAYERS:
     cfgs = [-1] + ([int(c) for c in sys.argv[2].split(',')] if len(sys.argv) > 2 else [])
     wsk = torch.zeros(32 << 20, dtype=torch.uint8, device=dev)
     ref_out = None
+    wino_ok = k == 3 and stride == 1 and not Cb and not ups and not refl
+    u = ops.wino_weight_transform(w) if (40 in cfgs and wino_ok) else None
     for cfg in cfgs:
+        if cfg == 40 and not wino_ok:
+            line += ' c40:   -  '
+            continue
         try:
             ws_arg = wsk if cfg >= 30 else None       # stream-K configs need the zero-filled scratch
             t = timeit(lambda: ops.conv2d(xa, w, out, src_b=xb, ksize=k, stride=stride, pad=pad, pad_mode=refl, upsample_a=bool(ups),
-                                          act=1, config=cfg, workspace=ws_arg))
+                                          act=1, config=cfg, workspace=ws_arg, weight_wino=u if cfg == 40 else None))
             line += f' c{cfg}:{flops/t/1e12:6.1f}'
             if cfg == -1:
                 ref_out = out.clone()
