@@ -111,6 +111,8 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=100)      # 0.33 s timed at 3.2 ms per step
     ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--blocks', type=int, default=25, help='how many times the timed block of `steps` steps is repeated; the median '
+                    'block is reported (ms_per_step), min / max beside it')
     ap.add_argument('--replay', type=int, default=4, help='replay triplets of the N=1 minibatch; every rank gets 1+replay triplets')
     ap.add_argument('--total-replay', type=int, default=None, help='shard a minibatch of 1+K triplets over the ranks instead '
                     '(8 GPUs, K=32: BASELINE config 4)')
@@ -212,17 +214,28 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        outputs, losses = step()
-    sync()
-    dt = time.perf_counter() - t0
-    if N > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    # The timed region of the contract -- barrier + synchronize, EXACTLY `steps` steps, barrier + synchronize, MAX over ranks -- is
+    # run `blocks` times back to back (default 25: ~1.7 s of GPU work at 3.3 ms per step, so that the driver's utilisation
+    # sampler sees the GPU busy) and the MEDIAN block is reported; min / max are printed beside it.  `steps` x `ms_per_step`
+    # describes one block.  (One 65 ms block, as in rounds 1-4, moved by +-1 % from run to run -- the size of every gain claimed
+    # since round 2.)
+    block_s = []
+    for _ in range(max(1, args.blocks)):
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            outputs, losses = step()
+        sync()
+        dt = time.perf_counter() - t0
+        if N > 1:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        block_s.append(dt)
+    ordered = sorted(block_s)
+    dt = ordered[len(ordered) // 2]
     ms = dt / args.steps * 1e3
+    ms_min, ms_max = ordered[0] / args.steps * 1e3, ordered[-1] / args.steps * 1e3
     value = (args.steps / dt) * (B / FRAME_TRIPLETS)
 
     # ---- SURVEY.md 8(d)'s end-to-end frame: pinned host batch -> adapt() (H2D inside) -> pose + losses on the host -------
@@ -349,6 +362,8 @@ def main():
                       32: 'conv3x3_sk_kernel<8, 16, true, 1, 64, 4, 2>', 33: 'conv3x3_sk_kernel<4, 16, true, 1, 64, 4, 2>',
                       34: 'conv3x3_sk_kernel<8, 16, false, 1, 32, 4, 1>', 35: 'conv3x3_sk_kernel<4, 16, false, 1, 32, 2, 2>',
                       36: 'conv3x3_sk_kernel<4, 16, true, 1, 32, 2, 2>', 37: 'conv3x3_sk_kernel<8, 16, true, 1, 32, 4, 1>'})
+        # Winograd F(2x2,3x3) kernels (conv_wino.hip): 16 MFMA MACs per 2x2 output tile and input channel instead of 36
+        names.update({40: 'conv3x3_wino8_kernel'})
         (kind, cfg), (fl, tt, cnt, nb) = max(agg.items(), key=lambda kv: kv[1][1])
         all_fl = sum(a[0] for a in agg.values())
         all_t = sum(a[1] for a in agg.values())
@@ -370,6 +385,23 @@ def main():
                 'avg_launch_us': round(tt / cnt * 1e6, 2), 'flops_per_launch_avg': fl / cnt,
                 'all_conv_launches': {'achieved': round(all_fl / all_t / 1e12, 2), 'time_ms_per_step': round(all_t * 1e3, 3),
                                       'gflop_per_step': round(all_fl / 1e9, 2)}}
+        if cfg == 40:
+            # `achieved` counts the ALGORITHMIC flops of the convolution (2 * M * Cout * 9 * Cin), as for every other
+            # kernel; this kernel EXECUTES 16/36 of them on the matrix pipe -- both fractions are stated
+            roof['algorithm'] = 'Winograd F(2x2,3x3): 16/36 of the direct MFMA count'
+            roof['executed_mfma_tflops'] = round(fl / tt / 1e12 * 16 / 36, 2)
+            roof['executed_mfma_frac'] = round(fl / tt / 1e12 * 16 / 36 / FP32_MFMA_PEAK_TFLOPS, 4)
+        # the dominant DIRECT kernel beside it (rounds 1-4's roofline row), and how the launches split
+        direct = [(kv[0][1], kv[1]) for kv in agg.items() if kv[0][1] != 40]
+        if direct and cfg == 40:
+            dcfg, (dfl, dtt, dcnt, dnb) = max(direct, key=lambda kv: kv[1][1])
+            roof['dominant_direct_kernel'] = {'kernel': names[dcfg], 'achieved': round(dfl / dtt / 1e12, 2),
+                                              'frac': round(dfl / dtt / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4), 'launches_per_step': dcnt,
+                                              'avg_launch_us': round(dtt / dcnt * 1e6, 2)}
+        wfl = sum(a[0] for (k_, c_), a in agg.items() if c_ == 40)
+        wt = sum(a[1] for (k_, c_), a in agg.items() if c_ == 40)
+        roof['all_conv_launches']['winograd'] = {'launches': sum(a[2] for (k_, c_), a in agg.items() if c_ == 40),
+                                                 'gflop_per_step': round(wfl / 1e9, 2), 'time_ms_per_step': round(wt * 1e3, 3)}
     cpu = None
     if rank == 0 and N == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(H, W, B)
@@ -377,13 +409,16 @@ def main():
         line = {
             'metric': 'online-adapt frames/sec @192x640 (1 triplet + K replay)',
             'value': round(value, 3), 'unit': 'frames/s', 'n_gpus': N, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'ms_per_step': round(ms, 3), 'ms_per_step_min': round(ms_min, 3), 'ms_per_step_max': round(ms_max, 3),
+            'timed_blocks': len(block_s), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic (uniform-random images, lr 1e-12)' if args.random_images else 'synthetic',
             'config': {'workload': f'DepthPosePrediction.adapt(steps={S}), {H}x{W}, 1 online + K={K} replay triplets '
                                    f'(global batch {B}); ResNet-18 depth+pose nets, closed-form random-init weights; '
                                    f'a frame = {FRAME_TRIPLETS} triplets (value = steps/s * B/{FRAME_TRIPLETS})',
                        'global_batch': B, 'replay_k': K, 'height': H, 'width': W, 'adapt_steps_per_frame': S,
                        'parallelism': f'dp{N}' if N > 1 else 'single', 'shards': counts,
+                       # by-sample sharding cannot beat the largest shard: the speed-up over one GPU is capped at B / max(shard)
+                       'shard_imbalance_speedup_cap': round(B / max(counts), 2),
                        'timed_region': 'minibatch resident in HBM -> adapt() -> ' + ('nothing read back' if args.no_readback else
                                        'cam_T_cam[0] and every loss scalar on the host (slam.py:181-188)'),
                        'boundary': 'opt-in host-output path (host_pose_output=True): pose + losses handed out as host tensors '
@@ -399,6 +434,10 @@ def main():
             line['also'] = also
         if e2e is not None:
             line.setdefault('also', {})['end_to_end'] = e2e
+            # SURVEY.md 8(d) defines the metric WITH the host -> device upload of the sample dict: stated at top level beside `value`
+            # (which, by the bench contract, starts with the minibatch resident in HBM)
+            line['value_end_to_end'] = e2e['frames_per_s']
+            line['ms_per_frame_end_to_end'] = e2e['ms_per_frame']
         print(json.dumps(line), flush=True)
     if N > 1:
         dist.destroy_process_group()

@@ -218,6 +218,8 @@ class Engine:
         self.use_side_stream = os.environ.get('CLSLAM_SIDE_STREAM', '1') != '0'
         # steps 2..S of adapt(steps=S) keep the frozen encoders' features (see forward)
         self.reuse_frozen_features = os.environ.get('CLSLAM_REUSE_FROZEN', '1') != '0'
+        # Winograd F(2x2,3x3) for the frozen encoders' 3x3 stride-1 convolutions (CLSLAM_NO_WINOGRAD=1: the direct kernels)
+        self.winograd = not os.environ.get('CLSLAM_NO_WINOGRAD')
 
     # ------------------------------------------------------------------------------------------
     # parameters
@@ -351,6 +353,10 @@ class Engine:
                     blk = SimpleNamespace(stride=stride if bi == 0 else 1, cin=cin if bi == 0 else cout, cout=cout)
                     blk.w1 = conv(p + '.conv1.weight'); blk.s1, blk.b1 = bn(p + '.bn1')
                     blk.w2 = conv(p + '.conv2.weight'); blk.s2, blk.b2 = bn(p + '.bn2')
+                    # frozen 3x3 stride-1 filters, transformed ONCE per load for the Winograd F(2x2,3x3) kernel (conv_wino.hip:
+                    # U = G g G^T in double, rounded once); clslam_conv2d picks the kernel per layer shape
+                    blk.u1 = ops.wino_weight_transform(blk.w1) if (blk.stride == 1 and self.winograd) else None
+                    blk.u2 = ops.wino_weight_transform(blk.w2) if self.winograd else None
                     blk.wd = None
                     if (p + '.downsample.0.weight') in sd:
                         blk.wd = conv(p + '.downsample.0.weight'); blk.sd, blk.bd = bn(p + '.downsample.1')
@@ -532,12 +538,12 @@ class Engine:
                         with self._on(aux):
                             ops.conv2d(x, blk.wd, res, scale=blk.sd, shift=blk.bd, ksize=1, stride=blk.stride, pad=0, act=ACT_NONE)
                         joined.record(aux)
-                ops.conv2d(x, blk.w1, t, scale=blk.s1, shift=blk.b1, ksize=3, stride=blk.stride, act=ACT_RELU)
+                ops.conv2d(x, blk.w1, t, scale=blk.s1, shift=blk.b1, ksize=3, stride=blk.stride, act=ACT_RELU, weight_wino=blk.u1)
                 if blk.wd is not None and joined is None:
                     ops.conv2d(x, blk.wd, res, scale=blk.sd, shift=blk.bd, ksize=1, stride=blk.stride, pad=0, act=ACT_NONE)
                 if joined is not None:
                     stream.wait_event(joined)
-                ops.conv2d(t, blk.w2, y, scale=blk.s2, shift=blk.b2, residual=res, ksize=3, act=ACT_RELU)
+                ops.conv2d(t, blk.w2, y, scale=blk.s2, shift=blk.b2, residual=res, ksize=3, act=ACT_RELU, weight_wino=blk.u2)
                 x = y
             feats.append(x)
         return feats

@@ -20,9 +20,8 @@ OBJ_DIR = CSRC / 'build'
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-DCLSLAM_DEVICE_BUILD=1',
          '-I', str(CSRC / 'include'), '-Wno-unused-result'] + os.environ.get('CLSLAM_HIPCC_EXTRA', '').split()
-# per-source flags.  conv_wino.hip names a0-a255 in its MFMA statements (intrin.h, AccFile): the compiler must not park its own
-# spills in the accumulator file
-FILE_FLAGS = {'conv_wino': ['-mllvm', '-amdgpu-spill-vgpr-to-agpr=0']}
+# per-source flags (none at present)
+FILE_FLAGS = {}
 
 
 def source_id() -> str:

@@ -230,7 +230,8 @@ static int launch_conv(ConvK k, hipStream_t stream) {
 namespace clslam { int conv3x3_patch_dispatch(const clslam_conv_desc* d, int cfg, hipStream_t stream);
                    int conv3x3_sk_dispatch(const clslam_conv_desc* d, int cfg, hipStream_t stream);
                    int conv3x3_wino_dispatch(const clslam_conv_desc* d, hipStream_t stream);
-                   int conv3x3_wino_supported(const clslam_conv_desc* d); }
+                   int conv3x3_wino_supported(const clslam_conv_desc* d);
+                   int conv3x3_wino_units_per_group(const clslam_conv_desc* d); }
 
 using namespace clslam;
 
@@ -249,8 +250,13 @@ extern "C" int clslam_conv2d_pick_config(const clslam_conv_desc* d) {
     const int M = d->batch * d->out_h * d->out_w;
     const bool bk32 = (Cin % 32 == 0) && (d->ch_b == 0 || d->ch_a % 32 == 0);
     // Winograd F(2x2,3x3) (conv_wino.hip, config 40) wherever the caller supplied the transformed filter: 2.25x fewer MFMAs
-    if (d->config != -2 && d->workspace != nullptr && conv3x3_wino_supported(d) && Cin >= 64 && d->ch_out >= 64 && !getenv("CLSLAM_NO_WINOGRAD"))
-        return 40;
+    // (config 40), where a persistent workgroup gets enough (tile, stage) units to amortise the kernel's
+    // fixed costs, or the direct kernels are at their weakest (the 6x20 layers): see conv3x3_wino_units_per_group
+    if (d->config != -2 && d->workspace != nullptr && conv3x3_wino_supported(d) && Cin >= 64 && d->ch_out >= 64 && !getenv("CLSLAM_NO_WINOGRAD")) {
+        static const int min_units = getenv("CLSLAM_WINO_MIN_UNITS") ? atoi(getenv("CLSLAM_WINO_MIN_UNITS")) : 8;
+        const int upg = conv3x3_wino_units_per_group(d);
+        if (upg >= min_units || (d->out_w <= 24 && upg >= 5)) return 40;
+    }
     // 3x3 stride-1: the LDS-patch kernel (conv_patch.hip).  Measured on MI355X (tools/bench_conv.py,
     // B=5 @192x640): 128 px x 16 ch tiles reach 80-104 TFLOP/s on the >= 48x160 layers, 64 px x 16 ch
     // tiles 65-95 TFLOP/s on the smaller ones, 64-px row-major runs 46-70 TFLOP/s on the 6x20 layers

@@ -111,7 +111,7 @@ __device__ __forceinline__ unsigned lds_addr(const float* lds_ptr) {
 }
 __device__ __forceinline__ void lds_dma16_at(const float* gsrc, float*, unsigned lds_base_addr, unsigned float_offset) {
     unsigned keep;
-    const unsigned dst = lds_base_addr + float_offset * 4u;
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base_addr + float_offset * 4u);     // (uniform; not always provably so)
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
 }
@@ -119,7 +119,7 @@ __device__ __forceinline__ void lds_dma16_at(const float* gsrc, float*, unsigned
 // (LDS address = M0 + offset + 16 * lane), so one M0 write and one address pair serve four transfers.
 __device__ __forceinline__ void lds_dma16_x4(const float* gsrc, float*, unsigned lds_base_addr, unsigned float_offset) {
     unsigned keep;
-    const unsigned dst = lds_base_addr + float_offset * 4u;
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base_addr + float_offset * 4u);     // (uniform; not always provably so)
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
                  "global_load_lds_dwordx4 %1, off offset:1024\n\tglobal_load_lds_dwordx4 %1, off offset:2048\n\t"
                  "global_load_lds_dwordx4 %1, off offset:3072\n\ts_mov_b32 m0, %0"
@@ -253,6 +253,7 @@ __device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0
 __device__ __forceinline__ void vmem_drain_visible() { __builtin_amdgcn_s_waitcnt(0x0F70); }
 __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // all but the eight youngest vector-memory operations of this wave (loads retire in issue order: MI355X_MICROARCH.md)
+__device__ __forceinline__ void dma_wait_keep4() { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
 __device__ __forceinline__ void dma_wait_keep8() { asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
 // workgroup barrier WITHOUT the vmcnt(0) hipcc attaches to __syncthreads() while LDS-DMA is in flight: LDS
 // reads/writes of this wave are drained (lgkmcnt), the DMA of the NEXT stage stays in flight across it
@@ -262,53 +263,6 @@ __device__ __forceinline__ void wg_barrier_keep_dma() {
     asm volatile("" ::: "memory");
 }
 
-
-// ---- 256 accumulators PINNED in the accumulator file: sixteen 32x32 fp32 tiles a[16P : 16P+15] -------------------------------
-// conv_wino.hip keeps 16 Winograd positions x (32 tiles x 32 channels) per wave = the whole accumulator file.  Through the
-// builtin hipcc has no slack (sixteen 16-register tuples fill a0-a255 exactly; every phi copy becomes a scratch spill -- measured:
-// 1.0-1.6 KB of scratch per lane and the MFMAs wrapped in v_accvgpr_write/scratch traffic), so the MFMAs name their registers.
-// Contract (cdna_hip_programming.md 5.7 item 4): every statement clobbers a0-a255, the file is compiled with
-// -mllvm -amdgpu-spill-vgpr-to-agpr=0 (csrc/build.py), and the compiler's own code may not contain v_accvgpr_* (checked by
-// tests/test_abi.py on the disassembly).  `AccFile` is empty here; the CPU emulator keeps the tiles in it.
-#define CLSLAM_AGPR_ALL "a0","a1","a2","a3","a4","a5","a6","a7","a8","a9","a10","a11","a12","a13","a14","a15","a16","a17","a18","a19","a20","a21","a22","a23","a24","a25","a26","a27","a28","a29","a30","a31","a32","a33","a34","a35","a36","a37","a38","a39","a40","a41","a42","a43","a44","a45","a46","a47","a48","a49","a50","a51","a52","a53","a54","a55","a56","a57","a58","a59","a60","a61","a62","a63","a64","a65","a66","a67","a68","a69","a70","a71","a72","a73","a74","a75","a76","a77","a78","a79","a80","a81","a82","a83","a84","a85","a86","a87","a88","a89","a90","a91","a92","a93","a94","a95","a96","a97","a98","a99","a100","a101","a102","a103","a104","a105","a106","a107","a108","a109","a110","a111","a112","a113","a114","a115","a116","a117","a118","a119","a120","a121","a122","a123","a124","a125","a126","a127","a128","a129","a130","a131","a132","a133","a134","a135","a136","a137","a138","a139","a140","a141","a142","a143","a144","a145","a146","a147","a148","a149","a150","a151","a152","a153","a154","a155","a156","a157","a158","a159","a160","a161","a162","a163","a164","a165","a166","a167","a168","a169","a170","a171","a172","a173","a174","a175","a176","a177","a178","a179","a180","a181","a182","a183","a184","a185","a186","a187","a188","a189","a190","a191","a192","a193","a194","a195","a196","a197","a198","a199","a200","a201","a202","a203","a204","a205","a206","a207","a208","a209","a210","a211","a212","a213","a214","a215","a216","a217","a218","a219","a220","a221","a222","a223","a224","a225","a226","a227","a228","a229","a230","a231","a232","a233","a234","a235","a236","a237","a238","a239","a240","a241","a242","a243","a244","a245","a246","a247","a248","a249","a250","a251","a252","a253","a254","a255"
-struct AccFile {};
-// one k-step of position P: a[16P:16P+15] += A(32 x 2) . B(2 x 32), A operand = a (32 rows), B operand = b (32 columns).  One
-// statement per MFMA: the statements are volatile, i.e. stay in program order, and the caller places its other work BETWEEN them --
-// the four k-steps of a position chain on one accumulator tile (64-cycle dependent latency = the issue interval), so whatever
-// issues between two of them is free, while work placed behind the fourth only overlaps that last MFMA.
-// GUARD: a leading s_nop for a compiler VALU write of an operand right in front of the statement (VALU -> MFMA SrcA/B is not padded
-// inside asm).
-template <int P, bool GUARD>
-__device__ __forceinline__ void acc_mfma(AccFile&, float a, float b) {
-    if constexpr (GUARD)
-        asm volatile("s_nop 1\n\tv_mfma_f32_32x32x2_f32 a[%c2:%c3], %0, %1, a[%c2:%c3]" : : "v"(a), "v"(b), "i"(16 * P), "i"(16 * P + 15) : CLSLAM_AGPR_ALL);
-    else
-        asm volatile("v_mfma_f32_32x32x2_f32 a[%c2:%c3], %0, %1, a[%c2:%c3]" : : "v"(a), "v"(b), "i"(16 * P), "i"(16 * P + 15) : CLSLAM_AGPR_ALL);
-}
-// tile P = 0 through the matrix pipe (C = 0, A = B = 0): runs beside the VALU work of the caller's epilogue instead of sixteen
-// v_accvgpr_write issue slots
-template <int P>
-__device__ __forceinline__ void acc_zero(AccFile&) {
-    const float z = 0.f;
-    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x2_f32 a[%c1:%c2], %0, %0, 0" : : "v"(z), "i"(16 * P), "i"(16 * P + 15) : CLSLAM_AGPR_ALL);
-}
-// tile P as sixteen VGPRs (call acc_settle() once between the last MFMA and the first read: XDL write -> v_accvgpr_read)
-__device__ __forceinline__ void acc_settle() { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }
-template <int P>
-__device__ __forceinline__ f32x16 acc_read(AccFile&) {
-    float r0, r1, r2, r3, r4, r5, r6, r7, r8, r9, r10, r11, r12, r13, r14, r15;
-    asm volatile("v_accvgpr_read_b32 %0, a%c16\n\tv_accvgpr_read_b32 %1, a%c17\n\tv_accvgpr_read_b32 %2, a%c18\n\tv_accvgpr_read_b32 %3, a%c19\n\t"
-                 "v_accvgpr_read_b32 %4, a%c20\n\tv_accvgpr_read_b32 %5, a%c21\n\tv_accvgpr_read_b32 %6, a%c22\n\tv_accvgpr_read_b32 %7, a%c23\n\t"
-                 "v_accvgpr_read_b32 %8, a%c24\n\tv_accvgpr_read_b32 %9, a%c25\n\tv_accvgpr_read_b32 %10, a%c26\n\tv_accvgpr_read_b32 %11, a%c27\n\t"
-                 "v_accvgpr_read_b32 %12, a%c28\n\tv_accvgpr_read_b32 %13, a%c29\n\tv_accvgpr_read_b32 %14, a%c30\n\tv_accvgpr_read_b32 %15, a%c31"
-                 : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3), "=v"(r4), "=v"(r5), "=v"(r6), "=v"(r7), "=v"(r8), "=v"(r9), "=v"(r10), "=v"(r11),
-                   "=v"(r12), "=v"(r13), "=v"(r14), "=v"(r15)
-                 : "i"(16 * P), "i"(16 * P + 1), "i"(16 * P + 2), "i"(16 * P + 3), "i"(16 * P + 4), "i"(16 * P + 5), "i"(16 * P + 6), "i"(16 * P + 7),
-                   "i"(16 * P + 8), "i"(16 * P + 9), "i"(16 * P + 10), "i"(16 * P + 11), "i"(16 * P + 12), "i"(16 * P + 13), "i"(16 * P + 14),
-                   "i"(16 * P + 15));
-    const f32x16 v = {r0, r1, r2, r3, r4, r5, r6, r7, r8, r9, r10, r11, r12, r13, r14, r15};
-    return v;
-}
 
 // 1/x to 1 ulp (v_rcp_f32) -- for the SSIM / projection quotients of the loss kernels, where an IEEE
 // division costs ~10 instructions and the last ulp is far below the 1e-4 parity bar

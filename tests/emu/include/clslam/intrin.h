@@ -89,6 +89,7 @@ inline void lds_dma16_at(const float* gsrc, float* lds_array, unsigned, unsigned
 inline void lds_dma16_x4(const float* gsrc, float* lds_array, unsigned, unsigned float_offset) { for (int i = 0; i < 4; ++i) memcpy(lds_array + float_offset + i * 256 + lane_id() * 4, gsrc + i * 256, 16); }
 inline void dma_wait_all() {}
 inline void dma_wait_keep8() {}
+inline void dma_wait_keep4() {}
 inline void sched_fence() {}
 inline int launder(int v) { return v; }
 inline void pin4(float4&, float4&, float4&, float4&) {}
@@ -122,17 +123,6 @@ inline void coherent_load4x2_x4(const float* p0, const float* p1, const float* p
     coherent_load4x2(p2, c[0], c[1]); coherent_load4x2(p3, d[0], d[1]);
 }
 inline void wg_barrier_keep_dma() { emu_sync_block(); }
-
-// pinned accumulators of conv_wino.hip: the emulator keeps the sixteen 32x32 tiles in the struct
-struct AccFile { f32x16 t[16]; };
-template <int P, bool GUARD>
-inline void acc_mfma(AccFile& f, float a, float b) { f.t[P] = mfma_32x32x2(a, b, f.t[P]); }
-template <int P>
-inline void acc_zero(AccFile& f) { for (int r = 0; r < 16; ++r) f.t[P][r] = 0.f; }
-inline void acc_settle() {}
-template <int P>
-inline f32x16 acc_read(AccFile& f) { return f.t[P]; }
-
 
 inline float wave_shfl_xor(float v, int mask) {
     const int l = lane_id();

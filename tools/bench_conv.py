@@ -87,7 +87,7 @@ for name, bm, Hi, Wi, Ca, Cb, Cout, k, stride, refl, ups, *rest in LAYERS:
     u = ops.wino_weight_transform(w) if (40 in cfgs and wino_ok) else None
     for cfg in cfgs:
         if cfg == 40 and not wino_ok:
-            line += ' c40:   -  '
+            line += f' c{cfg}:   -  '
             continue
         try:
             ws_arg = wsk if cfg >= 30 else None       # stream-K configs need the zero-filled scratch

@@ -7,13 +7,14 @@ sys.path.insert(0, str(Path(__file__).resolve().parents[1] / 'cl-slam_amd'))
 from clslam_hip import ops  # noqa: E402
 dev = torch.device('cuda:0')
 B, H, W, C = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+CFG = 40
 x = torch.randn(B, H, W, C, device=dev)
 w = torch.randn(C, 9, C, device=dev) * 0.05
 out = torch.empty(B, H, W, C, device=dev)
 ws = torch.zeros(48 << 20, dtype=torch.uint8, device=dev)
 u = ops.wino_weight_transform(w)
 for _ in range(3):
-    ops.conv2d(x, w, out, ksize=3, act=1, config=40, workspace=ws, weight_wino=u)
+    ops.conv2d(x, w, out, ksize=3, act=1, config=CFG, workspace=ws, weight_wino=u)
 torch.cuda.synchronize()
 G = 256
 off = (64 << 10) + G * 64 * 4 * 64 * 4
@@ -21,12 +22,12 @@ tr = ws[off:off + G * 64 * 8].view(torch.int64).view(G, 64).cpu()
 t0 = tr[:, 0].min()
 tr = (tr - t0).clamp_min(-1)
 import numpy as np
-a = tr.numpy().astype(np.float64) / 100.0      # s_memtime: 100 MHz constant clock -> us
+a = tr.numpy().astype(np.float64) / 100.0      # s_memtime ticks = shader cycles (tools/micro/mfma_clock.hip): columns in units of 100 cycles
 print('columns: start | prologue landed | prologue done | per unit: loop done, finish done, barrier passed  (us)')
-for g in (0, 1, 2, 100, 255):
+for g in (0, 1, 2, 3, 100, 101, 255):
     row = a[g]
     n = int((tr[g] >= 0).sum())
-    print(f'wg {g:3d}:', ' '.join(f'{v:6.2f}' for v in row[:min(n, 24)]))
+    print(f'wg {g:3d}:', ' '.join(f'{v - row[0]:6.1f}' for v in row[:min(n, 30)]))
 end = np.array([a[g][max(0, int((tr[g] > 0).sum()) - 1)] for g in range(G)])
 print('start  min/median/max:', a[:, 0].min(), np.median(a[:, 0]), a[:, 0].max())
 print('prologue landed median:', np.median(a[:, 1] - a[:, 0]), ' prologue transform median:', np.median(a[:, 2] - a[:, 1]))
