@@ -134,7 +134,8 @@ _SIGNATURES = {
     'clslam_diversity_commit': [fptr, fptr, i32, C.c_void_p, i32, i32, i32, i32, C.c_float, fptr, fptr, C.c_void_p,
                                 fptr, C.c_void_p],
 }
-_RESTYPES = {'clslam_last_error': C.c_char_p, 'clslam_build_id': C.c_char_p}
+_RESTYPES = {'clslam_last_error': C.c_char_p, 'clslam_last_error_string': C.c_char_p, 'clslam_build_id': C.c_char_p}
+ABI_VERSION = 101          # include/clslam_hip.h CLSLAM_ABI_VERSION: struct layouts / pointer types this binding was written for
 _SIZE_FNS = {'clslam_wino_weight_size': [i32, i32]}      # return size_t
 
 
@@ -160,6 +161,10 @@ class Library:
             fn = getattr(self.cdll, name)  # AttributeError if the symbol is not exported
             fn.argtypes = argtypes
             fn.restype = C.c_int
+        got = int(self.cdll.clslam_version())
+        if got != ABI_VERSION:      # a stale library would read the descriptors with another layout: refuse instead of corrupting memory
+            raise ClslamError(f'{path} implements ABI version {got}, this binding needs {ABI_VERSION}: rebuild it with '
+                              '`python cl-slam_amd/csrc/build.py`')
         self.is_device = bool(self.cdll.clslam_is_device_build())
         if require_device and not self.is_device:
             raise ClslamError(f'{path} is not a gfx950 device build')

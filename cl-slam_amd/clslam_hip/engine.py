@@ -1365,10 +1365,61 @@ class Engine:
         self._pose_decoder(st, feats[4])
         return st.pose
 
+    def _nhwc(self, f: torch.Tensor) -> torch.Tensor:
+        """(N,C,h,w) feature -> NHWC fp32 storage on the device (a view when it already is one: run_encoder's outputs are)"""
+        f = f.to(self.device, torch.float32)
+        return f.permute(0, 2, 3, 1).contiguous()
+
     def run_depth_decoder(self, input_features):
-        raise NotImplementedError('DepthDecoder.forward on external features is not part of the hot path; '
-                                  'use DepthPosePrediction.predict()/adapt()')
+        """models['depth_decoder'](features) (dpp.py:931-936 calls it on the encoder's five features; networks/depth_decoder.py:
+        51-71): {('disp', s): (N,1,H>>s,W>>s)} for s = 3..0 from the CURRENT decoder weights, by the same kernels as the step's
+        forward.  Inference only: no graph is recorded and nothing of a training step in flight is touched."""
+        self.pack_if_needed()
+        self._conv_workspace()
+        self.wait_training()
+        feats = [self._nhwc(f) for f in input_features]
+        n = feats[0].shape[0]
+        for k, f in enumerate(feats):
+            want = (n, self.H >> (k + 1), self.W >> (k + 1), NUM_CH_ENC[k])
+            if tuple(f.shape) != want:
+                raise ClslamError(f'depth_decoder: feature {k} must be (N, {want[3]}, {want[1]}, {want[2]}), got '
+                                  f'{tuple(input_features[k].shape)} (the engine is planned for {self.H}x{self.W} inputs)')
+        key = ('depth_decoder', n)
+        st = self._ws.get(key)
+        if st is None:
+            E = lambda *s: torch.empty(*s, device=self.device)  # noqa: E731
+            st = SimpleNamespace(x={}, disp=[E(n, self.H >> s, self.W >> s) for s in range(4)])
+            for i in range(4, -1, -1):
+                st.x[i, 0] = E(n, self.H >> (i + 1), self.W >> (i + 1), NUM_CH_DEC[i])
+                st.x[i, 1] = E(n, self.H >> i, self.W >> i, NUM_CH_DEC[i])
+            self._ws[key] = st
+        main, self._main = self._main, None          # no side-stream fork: a plain chain on the caller's stream
+        try:
+            self._depth_decoder(st, feats)
+        finally:
+            self._main = main
+        return {('disp', s): st.disp[s].unsqueeze(1).clone() for s in range(3, -1, -1)}
 
     def run_pose_decoder(self, last_features):
-        raise NotImplementedError('PoseDecoder.forward on external features is not part of the hot path; '
-                                  'use DepthPosePrediction.predict_pose()')
+        """models['pose_decoder']([features]) (dpp.py:957-965; networks/pose_decoder.py:37-54): (axis_angle, translation), each
+        (N, 2, 1, 3), from the last feature map of ONE pose-encoder pass."""
+        if len(last_features) != 1:
+            raise ClslamError('pose_decoder: the MI355X-native path implements num_input_features = 1')
+        self.pack_if_needed()
+        self._conv_workspace()
+        self.wait_training()
+        f4 = self._nhwc(last_features[0])
+        n = f4.shape[0]
+        want = (n, self.H >> 5, self.W >> 5, NUM_CH_ENC[4])
+        if tuple(f4.shape) != want:
+            raise ClslamError(f'pose_decoder: the feature must be (N, 512, {want[1]}, {want[2]}), got {tuple(last_features[0].shape)}')
+        key = ('pose_decoder', n)
+        st = self._ws.get(key)
+        if st is None:
+            E = lambda *s: torch.empty(*s, device=self.device)  # noqa: E731
+            st = SimpleNamespace(sq=E(n, want[1], want[2], 256), p0=E(n, want[1], want[2], 256), p1=E(n, want[1], want[2], 256),
+                                 pmean=E(n, 256), pose=E(n, 12))
+            self._ws[key] = st
+        self._pose_decoder(st, f4)
+        out = st.pose.clone().view(-1, 2, 1, 6)          # the 0.01 scale is applied by the head kernel (pose_decoder.py:50)
+        return out[..., :3], out[..., 3:]

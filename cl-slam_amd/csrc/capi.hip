@@ -84,4 +84,5 @@ extern "C" int clslam_version(void) { return 101; }
 #endif
 extern "C" const char* clslam_build_id(void) { return CLSLAM_BUILD_ID; }
 extern "C" const char* clslam_last_error(void) { return clslam::g_err; }
+extern "C" const char* clslam_last_error_string(void) { return clslam::g_err; }      // the name SURVEY.md 8(b) lists
 extern "C" int clslam_is_device_build(void) { return CLSLAM_DEVICE_BUILD; }

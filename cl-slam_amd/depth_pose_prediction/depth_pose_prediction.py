@@ -247,6 +247,8 @@ class DepthPosePrediction:
         self.host_pose_output = bool(host_pose_output)
         self._pose_host: Dict[int, Tensor] = {}
         self._pose_staged = None
+        self._dp_tags: Dict[Any, Tensor] = {}
+        self._dp_tag_staged = False
 
     # ============================================================
     # Data-parallel replay minibatch (new functionality; the reference has no multi-GPU adaptation)
@@ -264,6 +266,21 @@ class DepthPosePrediction:
         self.engine.async_tail = os.environ.get('CLSLAM_ASYNC_TAIL', '1') != '0'
         self.engine.data_parallel = True
         self.engine.noise_stream = int(shard_offset)     # identically seeded ranks draw different tie-break fields
+
+    def wait_training(self, stream=None) -> None:
+        """Order `stream` (default: torch's current stream) behind the training step in flight.  A training adapt() returns once
+        the caller's stream is ordered behind the forward and the last reads of its inputs; backward + optimizer step continue
+        on the engine's own stream (Engine.main_stream -- ONE per device and process: the steps of several predictors serialise
+        there).  Everything of this class that touches trainable state waits by itself; a caller that fences or times the step
+        with events on ITS stream calls this first (or synchronize())."""
+        self.engine.wait_training(stream)
+
+    def synchronize(self) -> None:
+        """Block the host until the training step in flight (incl. its optimizer step and, in data-parallel mode, the gradient
+        exchange) has completed."""
+        self.engine.wait_training()
+        if self.device.type == 'cuda':
+            torch.cuda.current_stream(self.device).synchronize()
 
     def gather_outputs(self, outputs: Dict[Any, Tensor]) -> Dict[Any, Tensor]:
         """Data-parallel mode: every rank's `outputs` shard concatenated in rank (= sample) order on every
@@ -358,12 +375,13 @@ class DepthPosePrediction:
             # engine.w/g/m/v) is ordered behind the step.  CLSLAM_DETACHED_TRAINING=0: the whole step on the caller's stream.
             eng = self.engine
             cur = em = released = None
-            if eng.detached_ok():
-                cur, em = eng.begin_detached()
-                if em is not None:      # still on the caller's stream: the output planes of the call's last forward
-                    eng.prealloc_outputs(training_data['rgb_aug', 0, 0].shape[0])
             failed = True
             try:
+                if eng.detached_ok():
+                    # (inside the try: a failed allocation in prealloc_outputs must not leave the engine in detached state)
+                    cur, em = eng.begin_detached()
+                    if em is not None:      # still on the caller's stream: the output planes of the call's last forward
+                        eng.prealloc_outputs(training_data['rgb_aug', 0, 0].shape[0])
                 with (torch.cuda.stream(em) if em is not None else _null_context()):
                     for it in range(steps):
                         eng._prealloc_armed = it == steps - 1      # the planes this call hands out: the caller's pool (below)
@@ -399,6 +417,8 @@ class DepthPosePrediction:
             finally:
                 if em is not None:
                     eng.end_detached(cur, released, failed=failed)
+                else:
+                    eng._caller, eng._prealloc, eng._prealloc_armed = None, None, False
             if self._pose_staged is not None:
                 # the event _staged_losses() waited for covers the pose copy issued just before the loss copy
                 T = self._pose_host[self._pose_staged].clone()
@@ -418,8 +438,10 @@ class DepthPosePrediction:
         eng.wait_training()
         bucketed = eng.grad_buckets > 1 and not eng.graph_preferred(1)
         for _ in range(steps):
-            losses = torch.zeros(18, device=self.device)
-            dist.all_reduce(losses, group=group)
+            ext = torch.cat([torch.zeros(18, device=self.device), self._dp_tag(0)])
+            dist.all_reduce(ext, group=group)
+            losses = ext[:18]
+            self._check_dp_tag(ext[18:21].cpu())
             self._losses_dev = losses
             eng._g.zero_()
             if bucketed:
@@ -696,45 +718,81 @@ class DepthPosePrediction:
                                                   noise=self._injected_noise, reuse_frozen=reuse_frozen, inputs_ready=ready)
         if ready is not None:
             self._upload_rest(inputs, ready[4])
+        ext = None
         if self._dp is not None and train:
             # only training steps are collective: predict() / adapt(online, None) on one rank (slam.py:178 on the
-            # rank that holds the online frame) must not pair up with another rank's gradient exchange
-            self._dp['dist'].all_reduce(losses, group=self._dp['group'])
+            # rank that holds the online frame) must not pair up with another rank's gradient exchange.
+            # Three extra scalars ride on the exchange: this rank's sample count and its gradient-exchange layout
+            # (code, code^2) -- _check_dp_tag() raises when the shard sizes do not add up to the global batch every rank
+            # scaled its loss weights by (a stale enable_data_parallel after the replay buffer grew), or when the ranks would
+            # issue different sequences of collectives (bucketed / whole / hipGraph), instead of corrupting or hanging silently.
+            ext = torch.cat([losses, self._dp_tag(B)])
+            self._dp['dist'].all_reduce(ext, group=self._dp['group'])
+            losses = ext[:18]
         self._losses_dev = losses
         if self.device.type == 'cuda':
             # ONE device->host copy of the 18 loss scalars per step (the NaN check of dpp.py:1115-1118 needs the loss
             # on the host anyway): the returned dict holds HOST tensors, so the caller's per-key `.cpu()` / `.item()`
             # (slam.py:186-188: one per key) cost nothing instead of a stream synchronisation each
             if self._loss_host is None:
-                self._loss_host = torch.empty(18, dtype=torch.float32, pin_memory=True)
+                self._loss_host = torch.empty(21, dtype=torch.float32, pin_memory=True)
                 self._loss_event = torch.cuda.Event()
             if train and self.host_pose_output:
                 if B not in self._pose_host:
                     self._pose_host[B] = torch.empty(2, B, 4, 4, dtype=torch.float32, pin_memory=True)
                 self._pose_host[B].copy_(self.engine.workspace(B).T, non_blocking=True)   # (2, B, 4, 4): frames -1, +1
                 self._pose_staged = B
-            self._loss_host.copy_(losses, non_blocking=True)
+            self._dp_tag_staged = ext is not None
+            if ext is not None:
+                self._loss_host.copy_(ext, non_blocking=True)
+            else:
+                self._loss_host[:18].copy_(losses, non_blocking=True)
             self._loss_event.record()
             if not train:
                 self._loss_event.synchronize()
-                loss_dict = self.engine.losses_dict(self._loss_host.clone())
+                loss_dict = self.engine.losses_dict(self._loss_host[:18].clone())
                 self._raise_on_nan(loss_dict)
                 if not self.host_pose_output:
                     loss_dict = self.engine.losses_dict(losses)
             else:
                 loss_dict = None         # adapt() builds it after the optimizer launch (see there)
         else:
+            if ext is not None:
+                self._check_dp_tag(ext[18:21])
             loss_dict = self.engine.losses_dict(losses)
             if not train:
                 self._raise_on_nan(loss_dict)
         return outputs, loss_dict
+
+    def _dp_tag(self, n_local: int) -> Tensor:
+        """(samples of this rank, c, c^2): c = the gradient-exchange layout this rank will use for the step"""
+        eng = self.engine
+        code = float(eng.grad_buckets * 2 + (1 if eng.graph_preferred(max(n_local, 1)) else 0))
+        key = (n_local, code)
+        hit = self._dp_tags.get(key)
+        if hit is None:
+            hit = self._dp_tags[key] = torch.tensor([float(n_local), code, code * code], device=self.device)
+        return hit
+
+    def _check_dp_tag(self, tag) -> None:
+        n, c, c2 = (float(v) for v in tag)
+        world = self._dp['dist'].get_world_size(self._dp['group'])
+        if int(round(n)) != self._dp['global_batch']:
+            raise RuntimeError(f'data-parallel step: the ranks hold {int(round(n))} samples but enable_data_parallel() was given a global '
+                               f'batch of {self._dp["global_batch"]} (call it again whenever the minibatch size changes): the loss '
+                               'weights of this step are wrong')
+        if abs(world * c2 - c * c) > 1e-3:
+            raise RuntimeError('data-parallel step: the ranks disagree on the gradient-exchange layout (CLSLAM_GRAD_BUCKETS / '
+                               'CLSLAM_HIPGRAPH differ between processes)')
 
     def _staged_losses(self) -> Dict[str, Tensor]:
         """the training step's loss dict: waits for the forward's staged copy only, not for the stream"""
         if self.device.type != 'cuda':
             return self.engine.losses_dict(self._losses_dev)
         self._loss_event.synchronize()
-        return self.engine.losses_dict(self._loss_host.clone())
+        if self._dp_tag_staged:
+            self._check_dp_tag(self._loss_host[18:21])
+        return self.engine.losses_dict(self._loss_host[:18].clone())
 
     def _raise_on_nan(self, loss_dict, undo_step: bool = False) -> None:
         """dpp.py:1115-1118"""

@@ -38,8 +38,12 @@ extern "C" {
 #define CLSLAM_PAD_REFLECT 1
 
 /* Library identification / error text (thread-local). */
+/* ABI version: 101 = clslam_conv_desc.weight_wino appended, clslam_wino_weight_*; 100 -> 101 also covers the double* dp_partial of
+ * clslam_warp_bwd / clslam_pose_bwd / clslam_loss_bwd*_pyramid (round 4).  Bindings check it before the first call.          */
+#define CLSLAM_ABI_VERSION 101
 int clslam_version(void);
 const char* clslam_last_error(void);
+const char* clslam_last_error_string(void); /* = clslam_last_error (the name SURVEY.md 8b lists) */
 /* 16 hex digits identifying the kernel sources the library was built from (csrc/build.py source_id()); "unstamped" for a
  * build that did not go through build.py.  bench.py pairs its timings with counter files of the same id only.           */
 const char* clslam_build_id(void);

@@ -46,3 +46,26 @@ def test_no_product_import_of_oracle():
     for f in (ROOT / 'cl-slam_amd').rglob('*.py'):
         src = f.read_text()
         assert not re.search(r'^\s*(from|import)\s+oracle\b', src, flags=re.M), f
+
+
+def test_binding_checks_the_abi_version():
+    """include/clslam_hip.h, the library and the ctypes binding agree on CLSLAM_ABI_VERSION (a descriptor grew a field in round 5,
+    four entry points changed a pointer type in round 4): a stale library is refused at load time instead of being handed
+    structures of another layout."""
+    import pytest
+    from clslam_hip import _lib
+    text = (ROOT / 'include' / 'clslam_hip.h').read_text()
+    declared = int(re.search(r'#define\s+CLSLAM_ABI_VERSION\s+(\d+)', text).group(1))
+    assert declared == _lib.ABI_VERSION
+    lib = _lib.Library(_lib.LIB_PATH, require_device=True)
+    assert lib.cdll.clslam_version() == declared
+    assert lib.cdll.clslam_last_error_string() == lib.cdll.clslam_last_error()
+    import ctypes as C
+    assert C.sizeof(_lib.ConvDesc) == 7 * 8 + 15 * 4 + 4 + 8 + 4 + 4 + 8 + 8 + 8      # ... + weight_wino (appended)
+    old = _lib.ABI_VERSION
+    try:
+        _lib.ABI_VERSION = old + 1
+        with pytest.raises(_lib.ClslamError, match='ABI version'):
+            _lib.Library(_lib.LIB_PATH, require_device=True)
+    finally:
+        _lib.ABI_VERSION = old

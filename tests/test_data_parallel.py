@@ -167,3 +167,37 @@ def test_two_ranks_nccl_equal_single_rank(tmp_path):
     assert float((r0['g'] - g).abs().max() / g.abs().max()) < 5e-2               # step 2 on a piecewise-smooth loss
     assert float((r0['w'] - p.engine.w.cpu()).abs().max()) < 4.5e-4              # at most a couple of lr-sized flips
     assert torch.allclose(r0['full_depth'], out['depth', 0].cpu(), rtol=2e-2, atol=0)
+
+
+def _stale_worker(rank, world, port, out_dir):
+    for p in (ROOT / 'cl-slam_amd', ROOT, ROOT / 'tests'):
+        sys.path.insert(0, str(p))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), CLSLAM_EMU_THREADS='4')
+    torch.set_num_threads(2)
+    import torch.distributed as dist
+    from clslam_hip import synth
+    from emu_util import use_backend
+    from predictor_util import make_predictor
+    use_backend('emu')
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    p = make_predictor(H, W, 1)
+    p.enable_data_parallel(3, rank)          # the ranks hold 1 + 1 samples: a global batch of 3 is stale
+    batch = {k: v[rank:rank + 1].clone() for k, v in synth.make_batch(2, H, W, seed=4).items()}
+    w0 = p.engine.w.clone()
+    msg = ''
+    try:
+        p.adapt(None, batch)
+    except RuntimeError as e:
+        msg = str(e)
+    torch.save({'msg': msg}, Path(out_dir) / f'stale{rank}.pt')
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_stale_global_batch_is_detected_on_every_rank(tmp_path):
+    """enable_data_parallel(global_batch, offset) has to be repeated whenever the minibatch grows; a stale value gives
+    every rank wrong 1/B loss weights.  The ranks' sample counts ride on the loss all-reduce and every rank raises."""
+    port = 29500 + os.getpid() % 2000
+    mp.spawn(_stale_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        assert 'global' in torch.load(tmp_path / f'stale{r}.pt')['msg']

@@ -18,7 +18,7 @@ ROOT = Path(__file__).resolve().parents[1]
 pytestmark = pytest.mark.gpu
 
 
-def _setup(rank, world, port):
+def _setup(rank, world, port, backend='gloo'):
     for p in (ROOT / 'cl-slam_amd', ROOT, ROOT / 'tests'):
         sys.path.insert(0, str(p))
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
@@ -27,7 +27,10 @@ def _setup(rank, world, port):
     from emu_util import use_backend
     torch.cuda.set_device(0)                       # both ranks on the one GPU
     use_backend('hip')
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+    if backend == 'nccl':          # RCCL: one rank per device (a single rank here: the box has one GPU)
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', 0))
+    else:
+        dist.init_process_group('gloo', rank=rank, world_size=world)
     return dist
 
 
@@ -37,11 +40,11 @@ def _lcd_weights():
     return _weights()[1]
 
 
-def _dp_worker(rank, world, port, H, W, counts, steps, frames, lcd, async_tail, out_dir, buckets=None, tag=''):
+def _dp_worker(rank, world, port, H, W, counts, steps, frames, lcd, async_tail, out_dir, buckets=None, tag='', backend='gloo'):
     os.environ['CLSLAM_ASYNC_TAIL'] = '1' if async_tail else '0'
     if buckets is not None:
         os.environ['CLSLAM_GRAD_BUCKETS'] = str(buckets)
-    dist = _setup(rank, world, port)
+    dist = _setup(rank, world, port, backend)
     from clslam_hip import synth
     from predictor_util import make_predictor
     B = sum(counts)
@@ -75,7 +78,7 @@ def _dp_worker(rank, world, port, H, W, counts, steps, frames, lcd, async_tail, 
     diverged_seen = not p.replicas_in_sync()
     if rank == 1:
         p.engine.w.view(torch.int32)[12345] ^= 1
-    p.engine.wait_training()
+    p.synchronize()
     torch.cuda.synchronize()
     cpu = lambda t: t.detach().cpu()      # noqa: E731
     torch.save({'in_sync': in_sync, 'diverged_seen': diverged_seen, 'full_depth': cpu(everything['depth', 0]),
@@ -165,6 +168,39 @@ def test_bucketed_gradient_exchange_is_bitwise_the_single_all_reduce(tmp_path):
             for name in ('g', 'w', 'm', 'full_depth', 'T'):
                 assert torch.equal(ref[k][name], got[k][name]), (key, k, name)
             assert torch.equal(ref[k]['first']['g'], got[k]['first']['g'])
+
+
+@pytest.mark.timeout(1500)
+def test_one_rank_rccl_is_bitwise_the_single_process_step(tmp_path):
+    """The RCCL code path on the one GPU of the box (review r4 item 6): backend 'nccl', world size 1 -- enable_data_parallel(B, 0),
+    the loss exchange with its consistency tag, the three bucketed ncclAllReduce calls issued on the TAIL stream beside the
+    persistent stream-K / Winograd kernels of the backward, `record_stream`-free bucket slices, the asynchronous tail on and
+    off; three frames of adapt(steps=2) at 192x640, B = 5.  A one-rank all-reduce is the identity, so gradients, weights, Adam
+    moments and outputs must be BITWISE those of the plain single-process step.  It measures no scaling (one rank); it is the
+    first time the collective library itself meets this stream schedule (rounds 1-4 ordered it through gloo's host-blocking
+    calls only).  profiles/r05_rccl1_timeline.txt shows which stream the RCCL kernels run on."""
+    sys.path.insert(0, str(ROOT / 'tests'))
+    from clslam_hip import synth
+    from emu_util import use_backend
+    from predictor_util import make_predictor
+    H, W, B, steps, frames = 192, 640, 5, 2, 3
+    for i, tail in enumerate((True, False)):
+        port = 29500 + (os.getpid() % 2000) + 41 + 2 * i
+        mp.start_processes(_dp_worker, args=(1, port, H, W, [B], steps, frames, False, tail, str(tmp_path), 3, '_rccl1', 'nccl'),
+                           nprocs=1, join=True, start_method='spawn')
+    got = [torch.load(tmp_path / f'rank0_{t}_rccl1.pt') for t in (1, 0)]
+    use_backend('hip')
+    p = make_predictor(H, W, B)
+    for f in range(frames):
+        p.set_tie_break_noise({s: v.cuda() for s, v in synth.make_noise(B, H, W, seed=8 + f).items()})
+        out, losses = p.adapt(None, {k: v.clone().pin_memory() for k, v in synth.make_batch(B, H, W, seed=4 + f).items()}, steps=steps)
+    p.synchronize()
+    for r in got:
+        assert r['in_sync']
+        for name, ref in (('g', p.engine.g), ('w', p.engine.w), ('m', p.engine.m), ('full_depth', out['depth', 0]), ('T', out['cam_T_cam', 0, 1])):
+            assert torch.equal(r[name], ref.detach().cpu()), name
+        for k, v in losses.items():
+            assert torch.equal(r['loss'][k].reshape(-1), v.detach().cpu().reshape(-1)), k
 
 
 # ---- CoVIO asynchronous predict / adapt mode ------------------------------------------------------------------------

@@ -395,3 +395,32 @@ def test_images_that_need_a_conversion_wait_for_the_whole_upload():
                 ref = got
             for a, b in zip(ref, got):
                 assert torch.equal(a, b), (kind, rep)
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_the_four_models_are_callables(backend):
+    """dpp.py:931-936 and :957-965 call the four networks one after the other -- models['depth_decoder'](features)
+    and models['pose_decoder']([features]) on the encoders' outputs.  Through the engine they give bitwise what predict() /
+    predict_pose() compute (the same kernels on the same weights), in the reference's output formats."""
+    dev = use_backend(backend)
+    p = make_predictor(H, W, 2)
+    batch = synth.make_batch(2, H, W, seed=31)
+    p._set_eval()
+    with torch.no_grad():
+        ref = p.predict(batch)
+        feats = p.models['depth_encoder'](batch['rgb_aug', 0, 0].to(dev))          # dpp.py:931: the augmented frame
+        assert [tuple(f.shape) for f in feats] == [(2, c, H >> (k + 1), W >> (k + 1)) for k, c in enumerate((64, 64, 128, 256, 512))]
+        disp = p.models['depth_decoder'](feats)
+        assert list(disp) == [('disp', s) for s in (3, 2, 1, 0)]               # depth_decoder.py:53-69: coarse to fine
+        for s in range(4):
+            assert disp['disp', s].shape == (2, 1, H >> s, W >> s)
+            assert torch.equal(disp['disp', s].cpu(), ref['disp', s].cpu())
+        # pose: frames (-1, 0) of sample 0, as dpp.py:951-965 feeds them
+        a, b = batch['rgb_aug', -1, 0][:1].to(dev), batch['rgb_aug', 0, 0][:1].to(dev)
+        pf = p.models['pose_encoder'](torch.cat([a, b], 1))
+        axis_angle, translation = p.models['pose_decoder']([pf])
+        assert axis_angle.shape == (1, 2, 1, 3) and translation.shape == (1, 2, 1, 3)
+        pose = p.engine.run_pose(a, b)                                        # (1, 12): what predict_pose() transforms
+        assert torch.equal(torch.cat([axis_angle, translation], -1).reshape(1, 12).cpu(), pose.cpu())
+        with pytest.raises(Exception, match='feature'):
+            p.models['depth_decoder'](feats[:4] + [feats[4][:, :, :1]])

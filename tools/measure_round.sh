@@ -40,6 +40,10 @@ prof() {   # name, env..., then bench args after --
 }
 prof 3streams CLSLAM_SIDE_STREAM=1
 prof serial CLSLAM_SIDE_STREAM=0
+# the RCCL code path on the one GPU (backend nccl, world size 1): which queue the all-reduce kernels run on, what they overlap
+rm -rf /tmp/prof_rccl1
+(cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/prof_rccl1 -o run -- python $OLDPWD/tools/rccl1_step.py 6 > /tmp/prof_rccl1.log 2>&1)
+{ tail -1 /tmp/prof_rccl1.log; python tools/timeline.py $(ls /tmp/prof_rccl1/*/*.db /tmp/prof_rccl1/*.db 2>/dev/null | head -1) -2; } > $OUT/${TAG}_rccl1_timeline.txt 2>&1
 brief() { python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print({k: d.get(k) for k in ('value', 'unit', 'ms_per_step', 'also')}, d['config']['workload'][:70])"; }
 {
   for r in 0 2 32; do echo "== 192x640 replay $r"; python bench.py --replay $r --steps 20 --warmup 5 --no-cpu-baseline | brief; done
@@ -50,6 +54,10 @@ brief() { python -c "import json,sys; d=json.loads(sys.stdin.read().strip().spli
 } > $OUT/${TAG}_other_configs.txt 2>&1
 BENCH_WGRAD=1 python tools/bench_conv.py 5 30,31,32,33 > $OUT/${TAG}_conv_microbench.txt 2>&1
 BENCH_WGRAD=0 python tools/bench_conv.py 1 30,31,32,33 > $OUT/${TAG}_conv_microbench_b1.txt 2>&1
+# Winograd F(2x2,3x3) (config 40) against the library's direct pick on the encoder layer shapes, B = 5 / 10 / 33
+{ for b in 5 10 33; do echo "== B = $b"; BENCH_WGRAD=0 BENCH_LAYERS=0,1,2,3,8 python tools/bench_conv.py $b 40 2>&1 | grep -v amdgpu; done; } > $OUT/${TAG}_wino_microbench.txt
+# gfx950 calibration the kernel designs rest on: MFMA vs same-wave / partner-wave VALU, LDS-DMA rate per CU
+{ for m in mfma_clock mfma_valu_share lds_dma_rate; do echo "== tools/micro/$m.hip"; hipcc --offload-arch=gfx950 -O3 -o /tmp/$m tools/micro/$m.hip 2>/dev/null && /tmp/$m; done; } > $OUT/${TAG}_micro_calibration.txt 2>&1
 python tools/bench_small.py > $OUT/${TAG}_small_kernels.txt 2>&1
 python tools/bench_reduce.py > $OUT/${TAG}_reduce.txt 2>&1
 BENCH_DGRAD=1 BENCH_WGRAD=0 python tools/bench_conv.py 5 20,21,22,26,30,31,32,33 2>&1 | grep -v amdgpu > $OUT/${TAG}_conv_microbench_dgrad.txt
