@@ -108,3 +108,85 @@ def test_lcd_pin_script_is_honest():
             n, H, W, seed = (int(v) for v in g[f'params_{i}'])
             img = synth.make_batch(n, H, W, seed=seed)['rgb', 1, 0]
             assert rel_err(feature_encoder(m.eval(), img), torch.from_numpy(g[f'features_{i}'])) < 1e-6
+
+
+# torchvision 0.11 `mobilenet_v3_small().features` -- every convolution / squeeze-excitation tensor with its shape, WRITTEN OUT AS
+# DATA (from the published architecture; torchvision itself is not installable here).  A BatchNorm2d(eps=1e-3,
+# momentum=0.01) with weight / bias / running_mean / running_var / num_batches_tracked follows every `...N.0.weight` convolution as
+# `...N.1.*`.  What is pinned: the 927,008 feature parameters (= torchvision's 2,542,856 minus the unused classifier: 576*1024 +
+# 1024 + 1024*1000 + 1000), the key list a real checkpoint must load into, BN eps, the make_divisible(exp // 4, 8) squeeze widths
+# (8, 24, 64, 64, 32, 40, 72, 144, 144).  What stays UNPINNED: the arithmetic against real torchvision with ImageNet weights.
+TORCHVISION_FEATURE_TENSORS = [
+    ('features.0.0.weight', (16, 3, 3, 3)), ('features.1.block.0.0.weight', (16, 1, 3, 3)),
+    ('features.1.block.1.fc1.weight', (8, 16, 1, 1)), ('features.1.block.1.fc1.bias', (8,)),
+    ('features.1.block.1.fc2.weight', (16, 8, 1, 1)), ('features.1.block.1.fc2.bias', (16,)),
+    ('features.1.block.2.0.weight', (16, 16, 1, 1)), ('features.2.block.0.0.weight', (72, 16, 1, 1)),
+    ('features.2.block.1.0.weight', (72, 1, 3, 3)), ('features.2.block.2.0.weight', (24, 72, 1, 1)),
+    ('features.3.block.0.0.weight', (88, 24, 1, 1)), ('features.3.block.1.0.weight', (88, 1, 3, 3)),
+    ('features.3.block.2.0.weight', (24, 88, 1, 1)), ('features.4.block.0.0.weight', (96, 24, 1, 1)),
+    ('features.4.block.1.0.weight', (96, 1, 5, 5)), ('features.4.block.2.fc1.weight', (24, 96, 1, 1)),
+    ('features.4.block.2.fc1.bias', (24,)), ('features.4.block.2.fc2.weight', (96, 24, 1, 1)),
+    ('features.4.block.2.fc2.bias', (96,)), ('features.4.block.3.0.weight', (40, 96, 1, 1)), ('features.5.block.0.0.weight',
+    (240, 40, 1, 1)), ('features.5.block.1.0.weight', (240, 1, 5, 5)), ('features.5.block.2.fc1.weight', (64, 240, 1, 1)),
+    ('features.5.block.2.fc1.bias', (64,)), ('features.5.block.2.fc2.weight', (240, 64, 1, 1)),
+    ('features.5.block.2.fc2.bias', (240,)), ('features.5.block.3.0.weight', (40, 240, 1, 1)),
+    ('features.6.block.0.0.weight', (240, 40, 1, 1)), ('features.6.block.1.0.weight', (240, 1, 5, 5)),
+    ('features.6.block.2.fc1.weight', (64, 240, 1, 1)), ('features.6.block.2.fc1.bias', (64,)),
+    ('features.6.block.2.fc2.weight', (240, 64, 1, 1)), ('features.6.block.2.fc2.bias', (240,)),
+    ('features.6.block.3.0.weight', (40, 240, 1, 1)), ('features.7.block.0.0.weight', (120, 40, 1, 1)),
+    ('features.7.block.1.0.weight', (120, 1, 5, 5)), ('features.7.block.2.fc1.weight', (32, 120, 1, 1)),
+    ('features.7.block.2.fc1.bias', (32,)), ('features.7.block.2.fc2.weight', (120, 32, 1, 1)),
+    ('features.7.block.2.fc2.bias', (120,)), ('features.7.block.3.0.weight', (48, 120, 1, 1)),
+    ('features.8.block.0.0.weight', (144, 48, 1, 1)), ('features.8.block.1.0.weight', (144, 1, 5, 5)),
+    ('features.8.block.2.fc1.weight', (40, 144, 1, 1)), ('features.8.block.2.fc1.bias', (40,)),
+    ('features.8.block.2.fc2.weight', (144, 40, 1, 1)), ('features.8.block.2.fc2.bias', (144,)),
+    ('features.8.block.3.0.weight', (48, 144, 1, 1)), ('features.9.block.0.0.weight', (288, 48, 1, 1)),
+    ('features.9.block.1.0.weight', (288, 1, 5, 5)), ('features.9.block.2.fc1.weight', (72, 288, 1, 1)),
+    ('features.9.block.2.fc1.bias', (72,)), ('features.9.block.2.fc2.weight', (288, 72, 1, 1)),
+    ('features.9.block.2.fc2.bias', (288,)), ('features.9.block.3.0.weight', (96, 288, 1, 1)),
+    ('features.10.block.0.0.weight', (576, 96, 1, 1)), ('features.10.block.1.0.weight', (576, 1, 5, 5)),
+    ('features.10.block.2.fc1.weight', (144, 576, 1, 1)), ('features.10.block.2.fc1.bias', (144,)),
+    ('features.10.block.2.fc2.weight', (576, 144, 1, 1)), ('features.10.block.2.fc2.bias', (576,)),
+    ('features.10.block.3.0.weight', (96, 576, 1, 1)), ('features.11.block.0.0.weight', (576, 96, 1, 1)),
+    ('features.11.block.1.0.weight', (576, 1, 5, 5)), ('features.11.block.2.fc1.weight', (144, 576, 1, 1)),
+    ('features.11.block.2.fc1.bias', (144,)), ('features.11.block.2.fc2.weight', (576, 144, 1, 1)),
+    ('features.11.block.2.fc2.bias', (576,)), ('features.11.block.3.0.weight', (96, 576, 1, 1)), ('features.12.0.weight',
+    (576, 96, 1, 1))
+]
+
+
+def test_lcd_encoder_shape_facts_of_torchvision_are_pinned():
+    from oracle.mobilenet import BN, MobileNetV3SmallFeatures, make_divisible
+    m = MobileNetV3SmallFeatures()
+    sd = m.state_dict()
+    assert sum(p.numel() for p in m.parameters()) == 927_008 == 2_542_856 - (576 * 1024 + 1024 + 1024 * 1000 + 1000)
+    want = []
+    for k, shape in TORCHVISION_FEATURE_TENSORS:
+        want.append((k, shape))
+        if k.endswith('.0.weight'):          # Conv2dNormActivation: the BatchNorm that follows
+            c = shape[0]
+            want += [(k[:-len('0.weight')] + '1.' + n, (c,)) for n in ('weight', 'bias', 'running_mean', 'running_var')]
+            want.append((k[:-len('0.weight')] + '1.num_batches_tracked', ()))
+    assert [(k, tuple(v.shape)) for k, v in sd.items()] == want
+    assert BN(8).eps == 1e-3 and BN(8).momentum == 0.01
+    se = [shape[0] for k, shape in TORCHVISION_FEATURE_TENSORS if k.endswith('fc1.weight')]
+    assert se == [8, 24, 64, 64, 32, 40, 72, 144, 144] == [make_divisible(e // 4, 8) for e in (16, 96, 240, 240, 120, 144, 288, 576, 576)]
+    # the product's encoder validates a state dict against exactly this key set
+    from clslam_hip import lcd
+    assert set(lcd.synthetic_state_dict()) == {k for k in sd if not k.endswith('num_batches_tracked')}
+
+
+def test_lcd_golden_generator_runs_whenever_torchvision_is_importable(tmp_path):
+    """tests/golden/make_lcd_golden.py pins the restatement against the REAL torchvision model the moment one is importable (a
+    maintainer's machine, a later image); here it must at least say so instead of silently producing nothing."""
+    import importlib.util
+    import subprocess
+    import sys
+    from pathlib import Path
+    script = Path(__file__).resolve().parent / 'golden' / 'make_lcd_golden.py'
+    have = importlib.util.find_spec('torchvision') is not None
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True)
+    if have:       # architecture pin (same closed-form state dict through torchvision's network and the restatement)
+        assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
+    else:
+        assert r.returncode == 3 and 'PARITY UNPINNED' in r.stdout
