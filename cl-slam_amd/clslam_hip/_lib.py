@@ -117,6 +117,8 @@ _SIGNATURES = {
     'clslam_u8_to_planar_f32': [C.c_void_p, fptr, i32, i32, i32, i32, C.c_void_p],
     'clslam_color_jitter_u8': [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, i32, i32, i32, C.POINTER(C.c_int), i32,
                                C.POINTER(C.c_double), C.c_void_p],
+    'clslam_color_jitter_f32_blocks': [i32, i32],
+    'clslam_color_jitter_f32': [fptr, fptr, C.c_void_p, fptr, i32, i32, i32, C.c_void_p],
     'clslam_avgpool_chunks': [i32],
     'clslam_global_avgpool': [fptr, fptr, fptr, i32, i32, i32, C.c_void_p],
     'clslam_se_gate': [fptr, fptr, fptr, fptr, fptr, fptr, i32, i32, i32, C.c_void_p],

@@ -107,3 +107,142 @@ def color_jitter(frames: torch.Tensor, order: Sequence[int], factors: Sequence[f
     _lib.get_lib().call('clslam_color_jitter_u8', _pa(frames, torch.uint8), _pa(out, torch.uint8), _pa(scratch, torch.uint8),
                         _pa(lsum, torch.int64), N, H, W, order_c, len(order), factors_c, _stream(frames))
     return out
+
+
+# ======================================================================================================================
+# The replay buffer's samples on the GPU (the path that runs on EVERY adapted frame: slam/slam.py:98 builds
+# the buffer with do_augmentation=True, slam/replay_buffer.py:186-235 `get` -> :263-291 `_get`)
+def jitter_params(draws, device) -> torch.Tensor:
+    """draws: one (order, factors) per image -- op ids in application order and the four factors by op id, as
+    get_random_color_jitter (datasets/utils.py:236-259) draws them -> the device records clslam_color_jitter_f32 reads."""
+    import numpy as np
+    rec = np.zeros(len(draws), dtype=[('order', np.int32, 4), ('f', np.float32, 4), ('omf', np.float32, 4)])
+    for i, (order, factors) in enumerate(draws):
+        o = [int(v) for v in order][:4]
+        rec['order'][i] = o + [-1] * (4 - len(o))
+        rec['f'][i] = [np.float32(float(v)) for v in factors]
+        rec['omf'][i] = [np.float32(1.0 - float(v)) for v in factors]        # 1.0 - ratio in double, then a C float (torch)
+    return torch.from_numpy(rec.view(np.uint8).reshape(-1).copy()).to(device)
+
+
+def color_jitter_tensor(images: torch.Tensor, params: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
+    """images (N,3,h,w) float32 in [0,1] on the library's device, params = jitter_params(...) with N records: torchvision's
+    tensor-path adjust_brightness / _contrast / _saturation / _hue chain per image (each with its own contrast mean)."""
+    if images.dtype != torch.float32 or images.dim() != 4 or images.shape[1] != 3:
+        raise _lib.ClslamError(f'color_jitter_tensor expects (N,3,h,w) float32 images, got {tuple(images.shape)} {images.dtype}')
+    images = images.contiguous()
+    N, _, h, w = images.shape
+    if params.numel() != N * 48:
+        raise _lib.ClslamError(f'color_jitter_tensor: {params.numel()} parameter bytes for {N} images (48 each)')
+    lib = _lib.get_lib()
+    out = torch.empty_like(images) if out is None else out
+    partial = torch.empty(max(N, 1) * lib.cdll.clslam_color_jitter_f32_blocks(h, w), device=images.device)
+    lib.call('clslam_color_jitter_f32', _p(images), _p(out), _pa(params, torch.uint8), _p(partial), N, h, w, _stream(images))
+    return out
+
+
+def draw_color_jitter(brightness=(0.8, 1.2), contrast=(0.8, 1.2), saturation=(0.8, 1.2), hue=(-.1, .1), rng=None):
+    """The draws of datasets/utils.py:236-259 from Python's `random` IN THE REFERENCE'S ORDER (four uniforms, then the shuffle of
+    the four-element transform list), so that a run seeded like the reference consumes the same random stream."""
+    import random
+    rng = random if rng is None else rng
+    factors = [rng.uniform(*brightness), rng.uniform(*contrast), rng.uniform(*saturation), rng.uniform(*hue)]
+    order = [BRIGHTNESS, CONTRAST, SATURATION, HUE]
+    rng.shuffle(order)
+    return order, factors
+
+
+class ReplaySampleBuilder:
+    """What ``ReplayBuffer._get`` (slam/replay_buffer.py:263-291) builds per replayed sample -- PNG -> RGB, the LANCZOS pyramid level
+    from level, ToTensor, one drawn colour jitter on every level -- with the pixels on the GPU: the host decodes the PNGs
+    (Pillow), the raw uint8 frames cross PCIe ONCE, pyramid and jitter are three kernels per level for all samples and frames.
+
+        build = ReplaySampleBuilder(height, width, scales, frames, device)
+        replay_buffer._get = build.get_one            # drop-in: same signature, same dict, image tensors on the GPU
+        samples = build.get_many(filenames)           # or: the K samples of a frame in one go (what `get` concatenates)
+
+    Non-image entries of the pickled sample (camera matrices, relative distances, index ...) are passed through unchanged.
+    """
+
+    def __init__(self, height: int, width: int, scales: Sequence[int] = (0, 1, 2, 3), frames: Sequence[int] = (0, -1, 1),
+                 device=None, do_augmentation: bool = True, cache_frames: int = 0) -> None:
+        self.height, self.width, self.scales, self.frames = int(height), int(width), tuple(scales), tuple(frames)
+        self.device = torch.device('cuda' if device is None else device)
+        self.do_augmentation = bool(do_augmentation)
+        self.pyramid = ImagePyramid(height, width, tuple(range(max(self.scales) + 1)))
+        # opt-in: keep the DECODED uint8 frames of the last `cache_frames` image files on the host (a replay buffer re-serves
+        # the same few hundred samples: a 1241x376 PNG costs ~7 ms to decode, its 1.4 MB cost nothing to keep)
+        self.cache_frames = int(cache_frames)
+        self._decoded: Dict = {}
+
+    def _decode(self, path):
+        import numpy as np
+        from PIL import Image
+        key = str(path)
+        hit = self._decoded.get(key)
+        if hit is not None:
+            return hit
+        img = np.asarray(Image.open(path).convert('RGB'))           # replay_buffer.py:271
+        if self.cache_frames > 0:
+            if len(self._decoded) >= self.cache_frames:
+                self._decoded.pop(next(iter(self._decoded)))
+            self._decoded[key] = img
+        return img
+
+    def get_many(self, filenames, include_batch: bool = True, rng=None):
+        """-> one dict per file, exactly the entries `_get(filename, include_batch)` returns."""
+        import pickle
+
+        import numpy as np
+        datas, raws, draws = [], [], []
+        for fn in filenames:
+            # the jitter is drawn BEFORE the file is read (replay_buffer.py:264-268): same random stream as the reference
+            draw = draw_color_jitter(rng=rng) if self.do_augmentation else None
+            with open(fn, 'rb') as f:
+                data = pickle.load(f)
+            datas.append(data)
+            for frame in self.frames:
+                raws.append(self._decode(data['rgb', frame]))
+                draws.append(draw)
+        if not raws:
+            return []
+        if len({r.shape for r in raws}) != 1:
+            raise _lib.ClslamError('replay samples with different raw image sizes in one batch')
+        host = torch.from_numpy(np.stack(raws))
+        if self.device.type == 'cuda':
+            host = host.pin_memory()
+        levels = self.pyramid(host.to(self.device, non_blocking=True))          # {s: (n_img,3,h,w) float}, bit-exact vs Pillow
+        aug = levels
+        if self.do_augmentation:
+            params = jitter_params(draws, self.device)
+            aug = {s: color_jitter_tensor(levels[s], params) for s in self.scales}
+        nf = len(self.frames)
+        for i, data in enumerate(datas):
+            for j, frame in enumerate(self.frames):
+                k = i * nf + j
+                for s in self.scales:
+                    rgb, rga = levels[s][k], aug[s][k]
+                    data['rgb', frame, s] = rgb.unsqueeze(0) if include_batch else rgb
+                    data['rgb_aug', frame, s] = rga.unsqueeze(0) if include_batch else rga
+                del data['rgb', frame]
+            if not include_batch:                                # replay_buffer.py:286-289
+                for key in data:
+                    if not ('rgb' in key or 'rgb_aug' in key):
+                        data[key] = data[key].squeeze(0)
+        return datas
+
+    def get_one(self, filename, include_batch: bool = True):
+        """``ReplayBuffer._get(filename, include_batch=True)``"""
+        return self.get_many([filename], include_batch)[0]
+
+
+def cat_dict(online: Dict, replay: Dict, device=None) -> Dict:
+    """slam/slam.py:300-309 (`_cat_dict`) for a replay dict whose image tensors already live on the GPU: entries present in both
+    dicts are concatenated there (the online sample's entries are uploaded; torch.cat refuses mixed devices)."""
+    out = {}
+    for k in online:
+        if k in replay:
+            a, b = online[k], replay[k]
+            dev = device if device is not None else (b.device if b.device.type != 'cpu' else a.device)
+            out[k] = torch.cat([a.to(dev, non_blocking=True), b.to(dev, non_blocking=True)])
+    return out

@@ -300,3 +300,147 @@ extern "C" int clslam_color_jitter_u8(const unsigned char* src, unsigned char* d
     }
     return check_launch("color_jitter_u8");
 }
+
+// =====================================================================================================================
+// The replay buffer's colour jitter: torchvision's TENSOR code path on float images in [0, 1] (slam/replay_buffer.py:264-265,
+// 281-283 after ToTensor; slam/slam.py:98 do_augmentation=True) -- functional_tensor.py of torchvision 0.11.1, operation by
+// operation (oracle/jitter_tensor.py is the checker): _blend = (ratio * a + (1 - ratio) * b).clamp(0, 1) in float32, gray =
+// 0.2989 r + 0.587 g + 0.114 b, contrast blends with the image's mean gray, hue = _rgb2hsv -> (h + f) % 1 -> _hsv2rgb.
+// Contraction is off for this file: every product and sum rounds where torch's separate kernels round.
+// One image = one (3, h, w) planar float plane set with ITS OWN op order and factors (a replayed sample draws one jitter for its
+// three frames and four scales; the contrast mean is per image).  Two launches for any number of images: pass 1 applies the ops
+// in front of `contrast` and leaves per-block sums of the gray value, pass 2 forms the mean (fixed order) and applies the chain.
+namespace clslam {
+
+struct JitterParams {        // per image, device memory: order[k] in {0 brightness, 1 contrast, 2 saturation, 3 hue, -1 end}
+    int order[4];
+    float f[4];              // factor as a C float, indexed by op id
+    float omf[4];            // (float)(1.0 - factor): torch forms 1.0 - ratio in double before the multiply
+};
+
+__device__ __forceinline__ float clamp01(float v) { return fminf(fmaxf(v, 0.f), 1.f); }
+__device__ __forceinline__ float gray_of(float r, float g, float b) { return (0.2989f * r + 0.587f * g) + 0.114f * b; }
+
+__device__ __forceinline__ void jitter_hue(float& r, float& g, float& b, float hf) {
+    // _rgb2hsv
+    const float maxc = fmaxf(r, fmaxf(g, b)), minc = fminf(r, fminf(g, b));
+    const bool eqc = maxc == minc;
+    const float cr = maxc - minc;
+    const float s = cr / (eqc ? 1.f : maxc);
+    const float crd = eqc ? 1.f : cr;
+    const float rc = (maxc - r) / crd, gc = (maxc - g) / crd, bc = (maxc - b) / crd;
+    const float hr = (maxc == r) ? (bc - gc) : 0.f;
+    const float hg = ((maxc == g) && (maxc != r)) ? ((2.0f + rc) - bc) : 0.f;
+    const float hb = ((maxc != g) && (maxc != r)) ? ((4.0f + gc) - rc) : 0.f;
+    float h = (hr + hg) + hb;
+    h = fmodf(h / 6.0f + 1.0f, 1.0f);
+    // (h + hue_factor) % 1.0: torch.remainder = fmod, then + 1 when the sign differs from the divisor's
+    float hh = fmodf(h + hf, 1.0f);
+    if (hh != 0.f && hh < 0.f) hh += 1.0f;
+    // _hsv2rgb
+    const float v = maxc;
+    const float h6 = hh * 6.0f;
+    const float fl = floorf(h6);
+    const float f = h6 - fl;
+    int i = (int)fl;
+    const float p = clamp01(v * (1.0f - s));
+    const float q = clamp01(v * (1.0f - f * s));
+    const float t = clamp01(v * (1.0f - (s * (1.0f - f))));
+    i = ((i % 6) + 6) % 6;
+    r = i == 0 ? v : i == 1 ? q : i == 2 ? p : i == 3 ? p : i == 4 ? t : v;
+    g = i == 0 ? t : i == 1 ? v : i == 2 ? v : i == 3 ? q : i == 4 ? p : p;
+    b = i == 0 ? p : i == 1 ? p : i == 2 ? t : i == 3 ? v : i == 4 ? v : q;
+}
+
+// ops [k0, k1) of the chain on one pixel; `mean` is used by the contrast op only
+__device__ __forceinline__ void jitter_ops(const JitterParams& P, int k0, int k1, float& r, float& g, float& b, float mean) {
+    for (int k = k0; k < k1; ++k) {
+        const int op = P.order[k];
+        if (op < 0) break;
+        const float f = P.f[op], omf = P.omf[op];
+        if (op == 0) {
+            r = clamp01(f * r + omf * 0.f); g = clamp01(f * g + omf * 0.f); b = clamp01(f * b + omf * 0.f);
+        } else if (op == 1) {
+            const float m = omf * mean;
+            r = clamp01(f * r + m); g = clamp01(f * g + m); b = clamp01(f * b + m);
+        } else if (op == 2) {
+            const float m = omf * gray_of(r, g, b);
+            r = clamp01(f * r + m); g = clamp01(f * g + m); b = clamp01(f * b + m);
+        } else {
+            jitter_hue(r, g, b, f);
+        }
+    }
+}
+
+__device__ __forceinline__ int jitter_contrast_pos(const JitterParams& P) {
+    for (int k = 0; k < 4; ++k) {
+        if (P.order[k] < 0) break;
+        if (P.order[k] == 1) return k;
+    }
+    return -1;
+}
+
+// grid (nblk, images).  partial[img][blk] = sum of the gray value in front of the contrast op over the block's pixels
+__global__ __launch_bounds__(256) void jitter_f32_sum_kernel(const float* __restrict__ src, const JitterParams* __restrict__ params,
+                                                             float* __restrict__ partial, int hw) {
+    __shared__ float red[4];
+    const int img = blockIdx.y;
+    const JitterParams P = params[img];
+    const int kc = jitter_contrast_pos(P);
+    if (kc < 0) return;
+    const float* base = src + (size_t)img * 3 * hw;
+    float acc = 0.f;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < hw; i += gridDim.x * 256) {
+        float r = base[i], g = base[hw + i], b = base[2 * hw + i];
+        jitter_ops(P, 0, kc, r, g, b, 0.f);
+        acc += gray_of(r, g, b);
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[(size_t)img * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void jitter_f32_apply_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                               const JitterParams* __restrict__ params, const float* __restrict__ partial,
+                                                               int nblk_sum, int hw) {
+    __shared__ float s_mean;
+    const int img = blockIdx.y;
+    const JitterParams P = params[img];
+    if (threadIdx.x == 0) {
+        float m = 0.f;
+        if (jitter_contrast_pos(P) >= 0) {
+            for (int k = 0; k < nblk_sum; ++k) m += partial[(size_t)img * nblk_sum + k];     // fixed order
+            m = m / (float)hw;
+        }
+        s_mean = m;
+    }
+    __syncthreads();
+    const float mean = s_mean;
+    const float* base = src + (size_t)img * 3 * hw;
+    float* out = dst + (size_t)img * 3 * hw;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < hw; i += gridDim.x * 256) {
+        float r = base[i], g = base[hw + i], b = base[2 * hw + i];
+        jitter_ops(P, 0, 4, r, g, b, mean);
+        out[i] = r; out[hw + i] = g; out[2 * hw + i] = b;
+    }
+}
+
+}  // namespace clslam
+
+extern "C" int clslam_color_jitter_f32_blocks(int h, int w) { return std::max(1, std::min(64, clslam::cdiv(h * w, 1024))); }
+
+extern "C" int clslam_color_jitter_f32(const float* src, float* dst, const void* params, float* partial, int n_images, int h, int w,
+                                       void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n_images == 0 || h * w == 0) return CLSLAM_OK;
+    CLSLAM_REQUIRE(src && dst && params && partial, "color_jitter_f32: null pointer");
+    CLSLAM_REQUIRE(n_images > 0 && n_images <= 65535 && h > 0 && w > 0, "color_jitter_f32: bad geometry");
+    const int nblk = clslam_color_jitter_f32_blocks(h, w);
+    hipLaunchKernelGGL(clslam::jitter_f32_sum_kernel, dim3(nblk, n_images), dim3(256), 0, stream, src, (const clslam::JitterParams*)params,
+                       partial, h * w);
+    const int nb2 = std::max(1, std::min(256, clslam::cdiv(h * w, 512)));
+    hipLaunchKernelGGL(clslam::jitter_f32_apply_kernel, dim3(nb2, n_images), dim3(256), 0, stream, src, dst,
+                       (const clslam::JitterParams*)params, partial, nblk, h * w);
+    return clslam::check_launch("color_jitter_f32");
+}

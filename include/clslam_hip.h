@@ -386,6 +386,17 @@ int clslam_u8_to_planar_f32(const unsigned char* src, float* planar, int batch, 
 int clslam_color_jitter_u8(const unsigned char* src, unsigned char* dst, unsigned char* scratch, unsigned long long* lsum,
                            int batch, int h, int w, const int* order, int n_ops, const double* factors, void* stream);
 
+/* The replay buffer's colour jitter (slam/replay_buffer.py:264-265,281-283, enabled by slam/slam.py:98): torchvision's TENSOR code path
+ * (transforms/functional_tensor.py 0.11.1: adjust_brightness / _contrast / _saturation / _hue of float images in [0,1]) applied AFTER
+ * ToTensor, one drawn transform per replayed sample for its three frames and four scales.  src / dst: n_images planar (3,h,w) float
+ * images of one size (dst may be src); params: n_images device records {int32 order[4] (op ids 0 brightness, 1 contrast, 2 saturation,
+ * 3 hue in application order, -1 = end); float factor[4] (by op id); float one_minus_factor[4] ((float)(1.0 - factor), formed in
+ * double like torch does)} = 48 bytes each; partial: n_images * clslam_color_jitter_f32_blocks(h,w) floats of scratch (the
+ * per-image mean gray value of `contrast`, summed in a fixed order).  PARITY UNPINNED against real torchvision (source absent).   */
+int clslam_color_jitter_f32_blocks(int h, int w);
+int clslam_color_jitter_f32(const float* src, float* dst, const void* params, float* partial, int n_images, int h, int w,
+                            void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Loop-closure feature encoder: MobileNetV3-small forward (loop_closure_detection/encoder.py:13-33:
  * torchvision mobilenet_v3_small cut at 'flatten', ImageNet mean/std normalisation).  The 1x1 convs

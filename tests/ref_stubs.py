@@ -120,17 +120,17 @@ def _torchvision():
         def __init__(self, fn): self.fn = fn
         def __call__(self, x): return self.fn(x)
 
-    def _blend(a, b, f):
-        return (f * a + (1 - f) * b).clamp(0, 1)
-
-    def _gray(x):
-        return (0.299 * x[..., 0:1, :, :] + 0.587 * x[..., 1:2, :, :] + 0.114 * x[..., 2:3, :, :])
-
-    # tensor versions (the replay buffer jitters tensors, replay_buffer.py:281-282); plain blends, hue left alone
-    F.adjust_brightness = lambda x, f: _blend(x, torch.zeros_like(x), f)
-    F.adjust_contrast = lambda x, f: _blend(x, _gray(x).mean(dim=(-3, -2, -1), keepdim=True), f)
-    F.adjust_saturation = lambda x, f: _blend(x, _gray(x), f)
-    F.adjust_hue = lambda x, f: x
+    # tensor versions (the replay buffer jitters TENSORS, replay_buffer.py:281-283): the restatement of torchvision 0.11.1's
+    # functional_tensor.py in oracle/jitter_tensor.py (torchvision itself is not installable here)
+    def _tensor_or(fn_name):
+        def call(x, f):
+            from oracle import jitter_tensor as jt
+            return getattr(jt, fn_name)(x, f)
+        return call
+    F.adjust_brightness = _tensor_or('adjust_brightness')
+    F.adjust_contrast = _tensor_or('adjust_contrast')
+    F.adjust_saturation = _tensor_or('adjust_saturation')
+    F.adjust_hue = _tensor_or('adjust_hue')
     T.InterpolationMode, T.Resize, T.ToTensor, T.ToPILImage, T.Compose, T.Lambda = (InterpolationMode, Resize, ToTensor,
                                                                                       ToPILImage, Compose, Lambda)
     T.Normalize = MagicMock()
