@@ -182,7 +182,9 @@ class ReplaySampleBuilder:
         hit = self._decoded.get(key)
         if hit is not None:
             return hit
-        img = np.asarray(Image.open(path).convert('RGB'))           # replay_buffer.py:271
+        img = torch.from_numpy(np.asarray(Image.open(path).convert('RGB')).copy())      # replay_buffer.py:271
+        if self.device.type == 'cuda' and self.cache_frames > 0:
+            img = img.pin_memory()                                  # page-locked ONCE (~40 ms): later uploads are asynchronous DMAs
         if self.cache_frames > 0:
             if len(self._decoded) >= self.cache_frames:
                 self._decoded.pop(next(iter(self._decoded)))
@@ -206,12 +208,13 @@ class ReplaySampleBuilder:
                 draws.append(draw)
         if not raws:
             return []
-        if len({r.shape for r in raws}) != 1:
+        if len({tuple(r.shape) for r in raws}) != 1:
             raise _lib.ClslamError('replay samples with different raw image sizes in one batch')
-        host = torch.from_numpy(np.stack(raws))
-        if self.device.type == 'cuda':
-            host = host.pin_memory()
-        levels = self.pyramid(host.to(self.device, non_blocking=True))          # {s: (n_img,3,h,w) float}, bit-exact vs Pillow
+        # one device staging block, one asynchronous copy per (page-locked) frame
+        stage = torch.empty((len(raws),) + tuple(raws[0].shape), dtype=torch.uint8, device=self.device)
+        for i, r in enumerate(raws):
+            stage[i].copy_(r, non_blocking=True)
+        levels = self.pyramid(stage)                                 # {s: (n_img,3,h,w) float}, bit-exact vs Pillow
         aug = levels
         if self.do_augmentation:
             params = jitter_params(draws, self.device)

@@ -65,6 +65,8 @@ python tools/bench_gpu_bound.py 2>&1 | grep 'K=' > $OUT/${TAG}_gpu_bound.txt
 python tools/bench_memo.py 2>&1 | grep -v amdgpu > $OUT/${TAG}_descriptor_memo.txt
 bash tools/dp2_gloo.sh > $OUT/${TAG}_dp2_gloo.txt 2>&1
 { python tools/soak.py 2000 4; python tools/soak.py 2000 0; } 2>&1 | grep -v amdgpu > $OUT/${TAG}_soak.txt
+# the REAL frame of the SLAM loop: descriptor pass + replay get (reference's host path / GPU ingest) + adapt + read-back
+python tools/real_frame.py 40 4 2>&1 | grep -v amdgpu > $OUT/${TAG}_real_frame.txt
 # the measured numbers the parity tests print (trajectory envelope through steps=5, backward ladder, configs 4 / 5 at full workload)
 python -m pytest tests/test_trajectory.py -q -m gpu -s 2>&1 | grep "^\[hip\|passed\|failed" > $OUT/${TAG}_trajectory.txt
 python -m pytest tests/test_backward_parity.py -q -m gpu -s 2>&1 | grep "hip \|    \|passed\|failed" > $OUT/${TAG}_backward_parity.txt

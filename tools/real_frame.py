@@ -103,9 +103,16 @@ builders = {'gpu ingest': ingest.ReplaySampleBuilder(H, W, SCALES, FRAMES, dev),
 pick = np.random.default_rng(1)
 
 
-def frame(mode):
+DETAIL = {}
+
+
+def frame(mode, detail=False):
+    sync = torch.cuda.synchronize if detail else (lambda: None)
+    tick = time.perf_counter
+    ta = tick()
     online = dict(online_host)
     feat = p.models['depth_encoder'](online['rgb', 0, 0].to(dev))[4].mean(-1).mean(-1).cpu()      # slam.py:143-147
+    sync()
     fns = [files[i] for i in pick.choice(STORE, K, replace=False)]
     t0 = time.perf_counter()
     if mode == 'reference get (host)':
@@ -117,10 +124,17 @@ def frame(mode):
         replay = {k: torch.cat([d[k] for d in datas]) for k in datas[0]}
         t1 = time.perf_counter()
         training = ingest.cat_dict(online, replay, dev)
+    sync()
+    t2 = tick()
     out, losses = p.adapt(None, training, steps=1)
+    sync()
+    t3 = tick()
     T = out['cam_T_cam', 0, 1][0, :].squeeze().cpu().numpy()
     vals = {k: float(v) for k, v in losses.items()}
     assert vals['loss'] == vals['loss'] and abs(T).max() < 1e3 and feat.shape == (1, 512)
+    if detail:
+        for name, v in (('descriptor', t0 - ta), ('get', t1 - t0), ('cat', t2 - t1), ('adapt', t3 - t2), ('read-back', tick() - t3)):
+            DETAIL[name] = DETAIL.get(name, 0.0) + v
     return t1 - t0
 
 
@@ -138,3 +152,8 @@ for mode in ('reference get (host)', 'gpu ingest', 'gpu ingest, decoded frames c
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n * 1e3
     print(f'  {mode:36s}: {dt:8.2f} ms per frame  ({1e3 / dt:6.1f} frames/s)   of which `get`: {tg / n * 1e3:7.2f} ms')
+    if mode != 'reference get (host)':
+        DETAIL.clear()
+        for _ in range(10):
+            frame(mode, detail=True)
+        print('      stage by stage, a synchronize between the stages (ms):', {k: round(v / 10 * 1e3, 2) for k, v in DETAIL.items()})
