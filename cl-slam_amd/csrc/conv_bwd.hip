@@ -410,7 +410,7 @@ __device__ __forceinline__ void adam_apply4(const AdamArgs& a, size_t idx, const
 
 template <bool ADAM>
 __global__ __launch_bounds__(256) void reduce_multi_kernel(const ReduceItem* __restrict__ items, AdamArgs ad) {
-    __shared__ float4 red[256];
+    __shared__ double redd[256][4];
     const bool update = ADAM && !(ad.guard && !(ad.guard[0] == ad.guard[0]));
     const ReduceItem it = items[blockIdx.y];
     // Lanes along the split axis (KL) by split count: the big-weight layers (most of the bytes) have <= 24
@@ -425,20 +425,24 @@ __global__ __launch_bounds__(256) void reduce_multi_kernel(const ReduceItem* __r
         if (KL == 1) {
             for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
                 const float4* src = reinterpret_cast<const float4*>(it.partial) + i;
-                float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+                // the split partials are summed in DOUBLE and rounded once (round 5): with up to several hundred fp32 partials per
+                // element the fp32 running sum was the largest single source of elementwise gradient noise -- what decides the
+                // SIGN of the near-zero entries, i.e. Adam's first lr * sign(g) updates (tests/test_teacher_forced_steps.py)
+                double sx = 0.0, sy = 0.0, sz = 0.0, sw = 0.0;
                 int k = 0;
                 for (; k + 4 <= it.splits; k += 4) {   // four independent loads in flight, summed in split order
                     const float4 v0 = src[(size_t)k * n4], v1 = src[(size_t)(k + 1) * n4];
                     const float4 v2 = src[(size_t)(k + 2) * n4], v3 = src[(size_t)(k + 3) * n4];
-                    s.x += v0.x; s.y += v0.y; s.z += v0.z; s.w += v0.w;
-                    s.x += v1.x; s.y += v1.y; s.z += v1.z; s.w += v1.w;
-                    s.x += v2.x; s.y += v2.y; s.z += v2.z; s.w += v2.w;
-                    s.x += v3.x; s.y += v3.y; s.z += v3.z; s.w += v3.w;
+                    sx += v0.x; sy += v0.y; sz += v0.z; sw += v0.w;
+                    sx += v1.x; sy += v1.y; sz += v1.z; sw += v1.w;
+                    sx += v2.x; sy += v2.y; sz += v2.z; sw += v2.w;
+                    sx += v3.x; sy += v3.y; sz += v3.z; sw += v3.w;
                 }
                 for (; k < it.splits; ++k) {
                     const float4 v = src[(size_t)k * n4];
-                    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+                    sx += v.x; sy += v.y; sz += v.z; sw += v.w;
                 }
+                float4 s = make_float4((float)sx, (float)sy, (float)sz, (float)sw);
                 s.x *= it.scale; s.y *= it.scale; s.z *= it.scale; s.w *= it.scale;
                 reinterpret_cast<float4*>(it.out)[i] = s;
                 if (ADAM && update) adam_apply4(ad, (size_t)(it.out - ad.g_base) + i * 4, s);
@@ -447,17 +451,18 @@ __global__ __launch_bounds__(256) void reduce_multi_kernel(const ReduceItem* __r
         }
         for (size_t i0 = (size_t)blockIdx.x * IL; i0 < n4; i0 += (size_t)gridDim.x * IL) {
             const size_t i = i0 + il;
-            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+            double sx = 0.0, sy = 0.0, sz = 0.0, sw = 0.0;
             if (i < n4)
                 for (int k = kl; k < it.splits; k += KL) {
                     const float4 v = reinterpret_cast<const float4*>(it.partial + (size_t)k * it.n)[i];
-                    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+                    sx += v.x; sy += v.y; sz += v.z; sw += v.w;
                 }
-            red[threadIdx.x] = s;
+            redd[threadIdx.x][0] = sx; redd[threadIdx.x][1] = sy; redd[threadIdx.x][2] = sz; redd[threadIdx.x][3] = sw;
             __syncthreads();
             if (kl == 0 && i < n4) {
-                float4 t = red[il];
-                for (int q = 1; q < KL; ++q) { const float4 v = red[q * IL + il]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+                double tx = redd[il][0], ty = redd[il][1], tz = redd[il][2], tw = redd[il][3];
+                for (int q = 1; q < KL; ++q) { const double* v = redd[q * IL + il]; tx += v[0]; ty += v[1]; tz += v[2]; tw += v[3]; }
+                float4 t = make_float4((float)tx, (float)ty, (float)tz, (float)tw);
                 t.x *= it.scale; t.y *= it.scale; t.z *= it.scale; t.w *= it.scale;
                 reinterpret_cast<float4*>(it.out)[i] = t;
                 if (ADAM && update) adam_apply4(ad, (size_t)(it.out - ad.g_base) + i * 4, t);
@@ -468,14 +473,15 @@ __global__ __launch_bounds__(256) void reduce_multi_kernel(const ReduceItem* __r
     }
     for (size_t i0 = (size_t)blockIdx.x * IL; i0 < it.n; i0 += (size_t)gridDim.x * IL) {
         const size_t i = i0 + il;
-        float s = 0.f;
+        double s = 0.0;
         if (i < it.n)
             for (int k = kl; k < it.splits; k += KL) s += it.partial[(size_t)k * it.n + i];
-        red[threadIdx.x].x = s;
+        redd[threadIdx.x][0] = s;
         __syncthreads();
         if (kl == 0 && i < it.n) {
-            float t = red[il].x;
-            for (int q = 1; q < KL; ++q) t += red[q * IL + il].x;
+            double td = redd[il][0];
+            for (int q = 1; q < KL; ++q) td += redd[q * IL + il][0];
+            const float t = (float)td;
             it.out[i] = t * it.scale;
             if (ADAM && update) adam_apply(ad, (size_t)(it.out - ad.g_base) + i, t * it.scale);
         }

@@ -140,10 +140,13 @@ def _run(backend, H, W, B, seed, capsys):
         # that of a different network for every realisation -- at 192x640, B = 1 that is step 3 (16-20 % of the updates have
         # flipped after step 2 for the oracle and the HIP path alike), at 64x128, B = 3 step 4 -- and the distances are those
         # between decorrelated trajectories: 3 realisations of the ORACLE then spread by x5 and more (printed), and a factor
-        # of 2 between two sets of three is noise.  There only the order of magnitude is held (x10).
+        # of 2 between two sets of three is noise.  Those steps are PRINTED, not asserted: every step 1..5 is held
+        # tightly from the float64 state instead (tests/test_teacher_forced_steps.py: no chaos accumulates there).
         saturated = do['disp0'] >= 2e-2
-        factor = 10.0 if saturated else 2.0
-        lines[-1] += '   [saturated: x10]' if saturated else ''
+        factor = 2.0
+        lines[-1] += '   [saturated: reported, not asserted -- tests/test_teacher_forced_steps.py holds this step]' if saturated else ''
+        if saturated:
+            continue
         for k in dh:
             env = do[k]
             if k == 'loss':
