@@ -69,6 +69,8 @@ bash tools/dp2_gloo.sh > $OUT/${TAG}_dp2_gloo.txt 2>&1
 python tools/real_frame.py 40 4 2>&1 | grep -v amdgpu > $OUT/${TAG}_real_frame.txt
 # the measured numbers the parity tests print (trajectory envelope through steps=5, backward ladder, configs 4 / 5 at full workload)
 python -m pytest tests/test_trajectory.py -q -m gpu -s 2>&1 | grep "^\[hip\|passed\|failed" > $OUT/${TAG}_trajectory.txt
+python -m pytest tests/test_teacher_forced_steps.py -q -m gpu -s 2>&1 | grep "^\[hip\|passed\|failed" > $OUT/${TAG}_teacher_forced.txt
+python tools/diag_flips.py 2>&1 | grep -v amdgpu > $OUT/${TAG}_flip_attribution.txt
 python -m pytest tests/test_backward_parity.py -q -m gpu -s 2>&1 | grep "hip \|    \|passed\|failed" > $OUT/${TAG}_backward_parity.txt
 python -m pytest tests/test_configs_4_5.py -q -s 2>&1 | grep "^\[config\|passed\|failed" > $OUT/${TAG}_configs_4_5.txt
 echo done
