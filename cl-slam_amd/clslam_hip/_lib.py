@@ -81,6 +81,7 @@ _SIGNATURES = {
     'clslam_pose_to_proj': [fptr, fptr, fptr, fptr, i32, C.c_void_p],
     'clslam_warp_fwd': [fptr, i32, i32, fptr, fptr, fptr, fptr, fptr, fptr, i32, i32, i32, C.c_float, C.c_float, C.c_void_p],
     'clslam_warp_fwd_pyramid': [C.POINTER(fptr), fptr, fptr, fptr, fptr, fptr, fptr, i32, i32, i32, C.c_float, C.c_float, C.c_void_p],
+    'clslam_warp_coords_pyramid': [C.POINTER(fptr), fptr, fptr, fptr, i32, i32, i32, C.c_float, C.c_float, C.c_void_p],
     'clslam_warp_cells_pyramid': [C.POINTER(fptr), fptr, fptr, C.c_void_p, i32, i32, i32, C.c_float, C.c_float, C.c_void_p],
     'clslam_warp_bwd_blocks': [i32, i32],
     'clslam_automask_pyramid': [fptr, fptr, fptr, fptr, fptr, i32, i32, i32, i32, C.c_void_p],

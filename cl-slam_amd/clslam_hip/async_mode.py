@@ -124,12 +124,15 @@ class AsyncAdaptation:
             except Exception as exc:
                 # Release the inference replica with an abort marker at its next receive -- but only when EVERY trainer is on
                 # this path: the marker travels by a collective over `group`, which all trainers have to post.  That is the
-                # case for RuntimeError('NaN loss') (the loss scalars are all-reduced before the check of dpp.py:1115-1118, so
-                # all trainers raise at the same step; the marker itself is the leader's, the broadcast source) and trivially
-                # with a single trainer.  A failure of ONE trainer among several (bad input, out of memory) is not agreed
-                # on: posting would leave an unmatched collective behind while the peers sit in the gradient all-reduce --
-                # this trainer just raises, the peers run into their communicator's timeout / `transfer_timeout_s`.
-                agreed = self.world == 2 or (isinstance(exc, RuntimeError) and 'NaN loss' in str(exc))
+                # case with a single trainer; for RuntimeError('NaN loss') (the loss scalars are all-reduced before the check of
+                # dpp.py:1115-1118, so all trainers raise at the same step); and for a failure of ONE trainer before its step's
+                # exchange (malformed input, a failed allocation): DepthPosePrediction.adapt() completes that step's collectives
+                # with a status word, the failing trainer's exception carries `dp_agreed` and its peers raise
+                # DataParallelPeerFailure at the same step.  Only a failure in the MIDDLE of a step's collectives is not agreed
+                # on -- that trainer just raises, the peers run into their communicator's timeout / `transfer_timeout_s`.
+                from depth_pose_prediction.depth_pose_prediction import DataParallelPeerFailure
+                agreed = (self.world == 2 or (isinstance(exc, RuntimeError) and 'NaN loss' in str(exc))
+                          or isinstance(exc, DataParallelPeerFailure) or bool(getattr(exc, 'dp_agreed', False)))
                 if agreed:
                     try:
                         self._post(frame, abort=True)

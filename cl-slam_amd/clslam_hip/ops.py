@@ -493,6 +493,14 @@ def warp_cells_pyramid(disps, inv_k, proj, cells, min_depth, max_depth):
     return cells
 
 
+def warp_coords_pyramid(disps, inv_k, proj, coords, min_depth, max_depth):
+    """diagnostic: coords (4,2,B,H,W,2) float32 = the clipped sampling position (ix, iy) in pixels"""
+    B, H, W = coords.shape[2], coords.shape[3], coords.shape[4]
+    _lib.get_lib().call('clslam_warp_coords_pyramid', _ptr4(disps), _p(inv_k), _p(proj), _p(coords), B, H, W,
+                        _nd(min_depth), _nd(max_depth), _stream(coords))
+    return coords
+
+
 def automask_pyramid(idmap, noise, rpmap, sel, partial, batch, H, W):
     _lib.get_lib().call('clslam_automask_pyramid', _p(idmap), _p(noise), _p(rpmap), _pa(sel, torch.uint8), _p(partial), 4,
                         batch, H, W, _stream(idmap))

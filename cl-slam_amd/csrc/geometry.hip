@@ -403,6 +403,48 @@ extern "C" int clslam_warp_cells_pyramid(const float* const* disp, const float* 
     return check_launch("warp_cells_pyramid");
 }
 
+// Second diagnostic twin (tests/test_warp_positions.py): the sampling POSITION itself, (ix, iy) in pixels after the border
+// clip, for every (scale, source frame, sample, pixel) -- the quantity the warped-image tolerance is derived from.
+__global__ __launch_bounds__(256) void warp_coords_kernel(Pyramid pyr, const float* __restrict__ Kinv,
+                                                          const float* __restrict__ P, float2* __restrict__ coords, int B, int H,
+                                                          int W, float da, float db, int dmode, int tilesX) {
+    const int b = blockIdx.y, sc = blockIdx.z;
+    const int ty = blockIdx.x / tilesX, tx = blockIdx.x - ty * tilesX;
+    const int x = tx * WF_TW + (int)(threadIdx.x & 63), y = ty * WF_TH + (int)(threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    const unsigned HW = (unsigned)(H * W);
+    const unsigned pix = __umul24((unsigned)y, (unsigned)W) + (unsigned)x;
+    const int h = pyr.h[sc], w = pyr.w[sc];
+    const float disp = upsample_disp(pyr.disp[sc] + (size_t)b * h * w, h, w, H, W, y, x);
+    const float dep = disp_to_depth_dev(disp, da, db, dmode);
+    const float* Ki = Kinv + (size_t)b * 16;
+    float X[3], cam[3];
+    backproject_px(Ki, (float)x, (float)y, dep, cam, X);
+#pragma unroll
+    for (int fi = 0; fi < 2; ++fi) {
+        float u, v, den;
+        project_px(P + ((size_t)fi * B + b) * 12, X, u, v, den);
+        const Sample s = sample_coords(u, v, H, W);
+        (coords + (((size_t)sc * 2 + fi) * B + b) * HW)[pix] = make_float2(s.ix, s.iy);
+    }
+}
+
+extern "C" int clslam_warp_coords_pyramid(const float* const* disp, const float* inv_k, const float* proj, float* coords,
+                                          int batch, int H, int W, float min_depth, float max_depth, void* stream) {
+    CLSLAM_REQUIRE(disp && inv_k && proj && coords, "warp_coords_pyramid: null");
+    CLSLAM_REQUIRE(!(min_depth <= 0.f && max_depth > 0.f), "warp_coords_pyramid: min_depth is None");
+    float a, b; int mode;
+    depth_mode(min_depth, max_depth, &a, &b, &mode);
+    Pyramid pyr;
+    pyr.n = 4;
+    for (int k = 0; k < 4; ++k) { pyr.disp[k] = disp[k]; pyr.h[k] = H >> k; pyr.w[k] = W >> k; }
+    if (!batch) return CLSLAM_OK;
+    const int tilesX = cdiv(W, WF_TW);
+    hipLaunchKernelGGL(warp_coords_kernel, dim3(tilesX * cdiv(H, WF_TH), batch, 4), dim3(256), 0, (hipStream_t)stream, pyr, inv_k,
+                       proj, reinterpret_cast<float2*>(coords), batch, H, W, a, b, mode, tilesX);
+    return check_launch("warp_coords_pyramid");
+}
+
 extern "C" int clslam_warp_bwd_blocks(int H, int W) { return std::max(1, std::min(256, cdiv(H * W, 1024))); }
 
 extern "C" int clslam_warp_bwd(const float* dpred, const float* disp_s, int h, int w, const float* src_m1,

@@ -98,6 +98,12 @@ class EngineAdam(optim.Adam):
         eng.adam_step_count = step
 
 
+class DataParallelPeerFailure(RuntimeError):
+    """adapt(): another rank of the data-parallel group failed before this step's exchange.  Raised on EVERY healthy rank at
+    the same step (the failed rank completes the step's collectives with a status word, see _dp_abort_step); the optimizer
+    step was applied on none of them, so the replicas are still identical."""
+
+
 class DepthPosePrediction:
     def __init__(self, dataset_config, config: Config, use_online: bool = False, reference_quirks: bool = True,
                  host_pose_output: Optional[bool] = None, upload_all_inputs: Optional[bool] = None):
@@ -249,6 +255,8 @@ class DepthPosePrediction:
         self._pose_staged = None
         self._dp_tags: Dict[Any, Tensor] = {}
         self._dp_tag_staged = False
+        self._dp_ext_cpu = None
+        self._dp_posted = 0      # collectives of the current training step that have gone out (agreed failure, _dp_abort_step)
 
     # ============================================================
     # Data-parallel replay minibatch (new functionality; the reference has no multi-GPU adaptation)
@@ -376,49 +384,66 @@ class DepthPosePrediction:
             eng = self.engine
             cur = em = released = None
             failed = True
+            self._dp_posted = 0
             try:
-                if eng.detached_ok():
-                    # (inside the try: a failed allocation in prealloc_outputs must not leave the engine in detached state)
-                    cur, em = eng.begin_detached()
-                    if em is not None:      # still on the caller's stream: the output planes of the call's last forward
-                        eng.prealloc_outputs(training_data['rgb_aug', 0, 0].shape[0])
-                with (torch.cuda.stream(em) if em is not None else _null_context()):
-                    for it in range(steps):
-                        eng._prealloc_armed = it == steps - 1      # the planes this call hands out: the caller's pool (below)
-                        # steps 2..S see the same minibatch through the same frozen, eval-mode encoders (dpp.py:308-313):
-                        # their features and the identity-reprojection maps are kept, only the decoders re-run
-                        if eng.graph_preferred(training_data['rgb_aug', 0, 0].shape[0]):
-                            # forward + backward replayed as one hipGraph (same kernels, same streams)
-                            outputs_eval, losses = self._process_batch(training_data, loss_weights, train=True, graphed=True,
-                                                                       copy_inputs=(it == 0), reuse_frozen=(it > 0),
-                                                                       want_outputs=(it == steps - 1))
-                            self.optimizer.zero_grad()
-                            self._reduce_gradients()
-                        else:
-                            outputs_eval, losses = self._process_batch(training_data, loss_weights, train=True,
-                                                                       reuse_frozen=(it > 0))
-                            self.optimizer.zero_grad()
-                            self._backward(training_data)
-                            released = eng.inputs_released if it == steps - 1 else None
-                        # dpp.py:1115-1118 aborts on a NaN loss before backward/step.  Checking there costs a full host
-                        # sync in the middle of the step (the GPU idles while the host enqueues the backward), and a
-                        # sync at the end of the step starves the GPU at the start of the next one.  Instead the
-                        # forward copies the loss to pinned host memory behind an event; backward and a device-
-                        # guarded Adam (no-op when the loss is NaN) are enqueued, and only then does the host wait
-                        # for THAT event -- the GPU still has the whole backward queued while the host goes on.
-                        self.optimizer.loss_guard = self._losses_dev[17:18]
-                        self.optimizer.step()
-                        self.optimizer.loss_guard = None
-                        losses = self._staged_losses()
-                        self._raise_on_nan(losses, undo_step=True)
-                        if not self.host_pose_output:        # reference behaviour: the loss dict lives on the device
-                            losses = self.engine.losses_dict(self._losses_dev)
-                failed = False
-            finally:
-                if em is not None:
-                    eng.end_detached(cur, released, failed=failed)
-                else:
-                    eng._caller, eng._prealloc, eng._prealloc_armed = None, None, False
+                try:
+                    if eng.detached_ok():
+                        # (inside the try: a failed allocation in prealloc_outputs must not leave the engine in detached state)
+                        cur, em = eng.begin_detached()
+                        if em is not None:      # still on the caller's stream: the output planes of the call's last forward
+                            eng.prealloc_outputs(training_data['rgb_aug', 0, 0].shape[0])
+                    with (torch.cuda.stream(em) if em is not None else _null_context()):
+                        for it in range(steps):
+                            self._dp_posted = 0
+                            eng._prealloc_armed = it == steps - 1      # the planes this call hands out: the caller's pool (below)
+                            # steps 2..S see the same minibatch through the same frozen, eval-mode encoders (dpp.py:308-313):
+                            # their features and the identity-reprojection maps are kept, only the decoders re-run
+                            if eng.graph_preferred(training_data['rgb_aug', 0, 0].shape[0]):
+                                # forward + backward replayed as one hipGraph (same kernels, same streams)
+                                outputs_eval, losses = self._process_batch(training_data, loss_weights, train=True, graphed=True,
+                                                                           copy_inputs=(it == 0), reuse_frozen=(it > 0),
+                                                                           want_outputs=(it == steps - 1))
+                                self.optimizer.zero_grad()
+                                self._reduce_gradients()
+                            else:
+                                outputs_eval, losses = self._process_batch(training_data, loss_weights, train=True,
+                                                                           reuse_frozen=(it > 0))
+                                self.optimizer.zero_grad()
+                                self._backward(training_data)
+                                released = eng.inputs_released if it == steps - 1 else None
+                            # dpp.py:1115-1118 aborts on a NaN loss before backward/step.  Checking there costs a full host
+                            # sync in the middle of the step (the GPU idles while the host enqueues the backward), and a
+                            # sync at the end of the step starves the GPU at the start of the next one.  Instead the
+                            # forward copies the loss to pinned host memory behind an event; backward and a device-
+                            # guarded Adam (no-op when the loss is NaN) are enqueued, and only then does the host wait
+                            # for THAT event -- the GPU still has the whole backward queued while the host goes on.
+                            self.optimizer.loss_guard = self._losses_dev[17:18]
+                            self.optimizer.step()
+                            self.optimizer.loss_guard = None
+                            try:
+                                losses = self._staged_losses()
+                            except DataParallelPeerFailure:
+                                self.engine.adam_step_count -= 1     # the guarded launch saw the peer's NaN: nothing was applied
+                                raise
+                            self._raise_on_nan(losses, undo_step=True)
+                            if not self.host_pose_output:        # reference behaviour: the loss dict lives on the device
+                                losses = self.engine.losses_dict(self._losses_dev)
+                    failed = False
+                finally:
+                    if em is not None:
+                        eng.end_detached(cur, released, failed=failed)
+                    else:
+                        eng._caller, eng._prealloc, eng._prealloc_armed = None, None, False
+            except DataParallelPeerFailure:
+                raise
+            except Exception as exc:
+                # A failure of THIS rank before any collective of the step went out (a malformed minibatch, a failed allocation):
+                # the peers are about to wait in the loss exchange.  Complete the step's collectives with the status word set, so
+                # that every rank raises now instead of sitting in its communicator's timeout.
+                if self._dp is not None and self._dp_posted == 0:
+                    self._dp_abort_step()
+                    exc.dp_agreed = True
+                raise
             if self._pose_staged is not None:
                 # the event _staged_losses() waited for covers the pose copy issued just before the loss copy
                 T = self._pose_host[self._pose_staged].clone()
@@ -429,6 +454,24 @@ class DepthPosePrediction:
             self.engine.pack_if_needed()
             outputs_eval, losses = self._process_batch(online_data, loss_weights, train=False)
         return outputs_eval, losses
+
+    def _dp_abort_step(self) -> None:
+        """The collectives of ONE training step, posted by a rank that cannot run it: the loss exchange carries NaN (every
+        rank's device-guarded Adam launch becomes a no-op, like dpp.py:1115-1118's abort) and the status word of _dp_tag, the
+        gradient exchange carries zeros.  The healthy ranks raise DataParallelPeerFailure behind their step."""
+        eng, dist, group = self.engine, self._dp['dist'], self._dp['group']
+        eng.wait_training()
+        ext = torch.cat([torch.full((18,), float('nan'), device=self.device), self._dp_tag(0)])
+        ext[21] = 1.0
+        dist.all_reduce(ext, group=group)
+        eng._g.zero_()
+        if eng.grad_buckets > 1 and not eng.graph_preferred(1):
+            for _name, lo, hi in eng.bucket_ranges():
+                dist.all_reduce(eng._g[lo:hi], group=group)
+        else:
+            dist.all_reduce(eng._g, group=group)
+        eng._g.zero_()
+        eng.grads_synced = False
 
     def _empty_shard_steps(self, steps: int):
         """adapt() of a data-parallel rank whose shard is empty: the same sequence of collectives as a rank with samples
@@ -441,7 +484,7 @@ class DepthPosePrediction:
             ext = torch.cat([torch.zeros(18, device=self.device), self._dp_tag(0)])
             dist.all_reduce(ext, group=group)
             losses = ext[:18]
-            self._check_dp_tag(ext[18:21].cpu())
+            self._check_dp_tag(ext[18:22].cpu())
             self._losses_dev = losses
             eng._g.zero_()
             if bucketed:
@@ -727,6 +770,7 @@ class DepthPosePrediction:
             # scaled its loss weights by (a stale enable_data_parallel after the replay buffer grew), or when the ranks would
             # issue different sequences of collectives (bucketed / whole / hipGraph), instead of corrupting or hanging silently.
             ext = torch.cat([losses, self._dp_tag(B)])
+            self._dp_posted += 1
             self._dp['dist'].all_reduce(ext, group=self._dp['group'])
             losses = ext[:18]
         self._losses_dev = losses
@@ -735,7 +779,7 @@ class DepthPosePrediction:
             # on the host anyway): the returned dict holds HOST tensors, so the caller's per-key `.cpu()` / `.item()`
             # (slam.py:186-188: one per key) cost nothing instead of a stream synchronisation each
             if self._loss_host is None:
-                self._loss_host = torch.empty(21, dtype=torch.float32, pin_memory=True)
+                self._loss_host = torch.empty(22, dtype=torch.float32, pin_memory=True)
                 self._loss_event = torch.cuda.Event()
             if train and self.host_pose_output:
                 if B not in self._pose_host:
@@ -757,26 +801,29 @@ class DepthPosePrediction:
             else:
                 loss_dict = None         # adapt() builds it after the optimizer launch (see there)
         else:
-            if ext is not None:
-                self._check_dp_tag(ext[18:21])
+            self._dp_ext_cpu = ext      # checked behind the step's gradient exchange like on the GPU (_staged_losses)
             loss_dict = self.engine.losses_dict(losses)
             if not train:
                 self._raise_on_nan(loss_dict)
         return outputs, loss_dict
 
     def _dp_tag(self, n_local: int) -> Tensor:
-        """(samples of this rank, c, c^2): c = the gradient-exchange layout this rank will use for the step"""
+        """(samples of this rank, c, c^2, failed): c = the gradient-exchange layout this rank will use for the step; failed = 1
+        from a rank that could not run the step (_dp_abort_step)"""
         eng = self.engine
         code = float(eng.grad_buckets * 2 + (1 if eng.graph_preferred(max(n_local, 1)) else 0))
         key = (n_local, code)
         hit = self._dp_tags.get(key)
         if hit is None:
-            hit = self._dp_tags[key] = torch.tensor([float(n_local), code, code * code], device=self.device)
+            hit = self._dp_tags[key] = torch.tensor([float(n_local), code, code * code, 0.0], device=self.device)
         return hit
 
     def _check_dp_tag(self, tag) -> None:
-        n, c, c2 = (float(v) for v in tag)
+        n, c, c2, failed = (float(v) for v in tag)
         world = self._dp['dist'].get_world_size(self._dp['group'])
+        if failed > 0.5:
+            raise DataParallelPeerFailure(f'data-parallel step: {int(round(failed))} peer rank(s) failed before the exchange (their own '
+                                          'exception says why); the step was applied on no rank')
         if int(round(n)) != self._dp['global_batch']:
             raise RuntimeError(f'data-parallel step: the ranks hold {int(round(n))} samples but enable_data_parallel() was given a global '
                                f'batch of {self._dp["global_batch"]} (call it again whenever the minibatch size changes): the loss '
@@ -788,10 +835,13 @@ class DepthPosePrediction:
     def _staged_losses(self) -> Dict[str, Tensor]:
         """the training step's loss dict: waits for the forward's staged copy only, not for the stream"""
         if self.device.type != 'cuda':
+            if self._dp_ext_cpu is not None:
+                ext, self._dp_ext_cpu = self._dp_ext_cpu, None
+                self._check_dp_tag(ext[18:22])
             return self.engine.losses_dict(self._losses_dev)
         self._loss_event.synchronize()
         if self._dp_tag_staged:
-            self._check_dp_tag(self._loss_host[18:21])
+            self._check_dp_tag(self._loss_host[18:22])
         return self.engine.losses_dict(self._loss_host[:18].clone())
 
     def _raise_on_nan(self, loss_dict, undo_step: bool = False) -> None:
@@ -812,11 +862,13 @@ class DepthPosePrediction:
 
     def _allreduce(self, t: Tensor) -> None:
         """sum over the ranks, on torch's current stream (the engine calls it per gradient bucket on its tail stream)"""
+        self._dp_posted += 1
         self._dp['dist'].all_reduce(t, group=self._dp['group'])
 
     def _reduce_gradients(self) -> None:
         if self._dp is not None and not self.engine.grads_synced:
             with self.engine.training_stream():     # the tail stream when the engine left the reduction there
+                self._dp_posted += 1
                 self._dp['dist'].all_reduce(self.engine._g, group=self._dp['group'])
         self.engine.grads_synced = False
 

@@ -211,6 +211,11 @@ int clslam_warp_fwd_pyramid(const float* const* disp, const float* src_m1, const
  * x0 | y0 << 12 | (x not clipped) << 24 | (y not clipped) << 25; same arguments as clslam_warp_fwd_pyramid.          */
 int clslam_warp_cells_pyramid(const float* const* disp, const float* inv_k, const float* proj, int* cells, int batch, int H,
                               int W, float min_depth, float max_depth, void* stream);
+/* Diagnostic: the sampling positions themselves -- coords (4, 2, batch, H, W, 2) float = (ix, iy) in pixels of the source frame
+ * after grid_sample's border clip (the value the four taps are weighted by); same arguments as clslam_warp_cells_pyramid.
+ * tests/test_warp_positions.py bounds them against the float64 oracle, which is what the warped-image tolerance derives from. */
+int clslam_warp_coords_pyramid(const float* const* disp, const float* inv_k, const float* proj, float* coords, int batch, int H,
+                               int W, float min_depth, float max_depth, void* stream);
 int clslam_warp_bwd_blocks(int H, int W);
 /* ddisp_up (B,H,W) = dL/d(upsampled disparity); dp_partial [B][nblk][24] block sums of dL/dproj */
 int clslam_warp_bwd(const float* dpred, const float* disp_s, int h, int w, const float* src_m1, const float* src_p1,

@@ -127,3 +127,51 @@ def test_failed_trainer_releases_the_inference_replica(tmp_path):
     mp.start_processes(_abort_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True, start_method='spawn')
     assert 'NaN loss' in (tmp_path / 'rank1.txt').read_text()
     assert 'training replica failed' in (tmp_path / 'rank0.txt').read_text()
+
+
+def _two_trainer_abort_worker(rank, world, port, out_dir):
+    for p in (ROOT / 'cl-slam_amd', ROOT, ROOT / 'tests'):
+        sys.path.insert(0, str(p))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), CLSLAM_EMU_THREADS='2')
+    torch.set_num_threads(1)
+    import time
+    import torch.distributed as dist
+    from clslam_hip import synth
+    from clslam_hip.async_mode import AsyncAdaptation
+    from emu_util import use_backend
+    from predictor_util import make_predictor
+    use_backend('emu')
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    trainers = dist.new_group([1, 2])               # (every rank creates every group)
+    p = make_predictor(H, W, 1)
+    am = AsyncAdaptation(p, sync_every=1, trainer_group=trainers, trainer_global_batch=2, trainer_shard_offset=max(rank - 1, 0),
+                         transfer_timeout_s=300.0)
+    what, t0 = 'finished', time.monotonic()
+    try:
+        for f in range(2):
+            online = synth.make_batch(1, H, W, seed=60 + f)
+            training = None
+            if rank >= 1:
+                training = {k: v[rank - 1:rank].clone() for k, v in synth.make_batch(2, H, W, seed=80 + f).items()}
+                if rank == 2 and f == 1:            # ONE of the two trainers gets a malformed minibatch
+                    del training['rgb', 1, 0]
+            am.step(f, online, training)
+        am.flush()
+    except Exception as e:          # noqa: BLE001
+        what = f'{type(e).__name__}: {e}'
+    (Path(out_dir) / f'rank{rank}.txt').write_text(f'{time.monotonic() - t0:.1f} s | {what}')
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(1200)
+def test_one_failed_trainer_of_two_is_agreed_on(tmp_path):
+    """two training replicas, one fails before its step's exchange.  The failing trainer completes the
+    step's collectives with a status word (DepthPosePrediction._dp_abort_step), its peer raises DataParallelPeerFailure at the
+    same step, both post the abort marker and the inference replica is released -- nobody waits for a communicator timeout."""
+    port = 29500 + (os.getpid() % 2000) + 17
+    mp.start_processes(_two_trainer_abort_worker, args=(3, port, str(tmp_path)), nprocs=3, join=True, start_method='spawn')
+    texts = [(tmp_path / f'rank{r}.txt').read_text() for r in range(3)]
+    assert 'training replica failed' in texts[0], texts
+    assert 'DataParallelPeerFailure' in texts[1], texts
+    assert 'KeyError' in texts[2], texts
+    assert all(float(t.split(' s |')[0]) < 240 for t in texts), texts

@@ -201,3 +201,54 @@ def test_stale_global_batch_is_detected_on_every_rank(tmp_path):
     mp.spawn(_stale_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     for r in range(2):
         assert 'global' in torch.load(tmp_path / f'stale{r}.pt')['msg']
+
+
+def _peer_failure_worker(rank, world, port, out_dir):
+    for p in (ROOT / 'cl-slam_amd', ROOT, ROOT / 'tests'):
+        sys.path.insert(0, str(p))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), CLSLAM_EMU_THREADS='4')
+    torch.set_num_threads(2)
+    import time
+    import torch.distributed as dist
+    from clslam_hip import synth
+    from emu_util import use_backend
+    from predictor_util import make_predictor
+    use_backend('emu')
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    p = make_predictor(H, W, 1)
+    p.enable_data_parallel(2, rank)
+    full = synth.make_batch(2, H, W, seed=4)
+    batch = {k: v[rank:rank + 1].clone() for k, v in full.items()}
+    p.adapt(None, dict(batch))                      # a good step first
+    w1, steps1 = p.engine.w.clone(), p.engine.adam_step_count
+    bad = dict(batch)
+    if rank == 1:
+        del bad['rgb_aug', -1, 0]                   # this rank's minibatch is malformed: it fails before any collective
+    t0 = time.monotonic()
+    kind, msg, agreed = '', '', False
+    try:
+        p.adapt(None, bad)
+    except Exception as e:          # noqa: BLE001
+        kind, msg, agreed = type(e).__name__, str(e), bool(getattr(e, 'dp_agreed', False))
+    waited = time.monotonic() - t0
+    same = bool(torch.equal(p.engine.w, w1)) and p.engine.adam_step_count == steps1
+    out, _ = p.adapt(None, dict(batch))             # the group is still in step: the next good step pairs up again
+    torch.save({'kind': kind, 'msg': msg, 'agreed': agreed, 'waited': waited, 'same': same, 'w': p.engine.w.clone()},
+               Path(out_dir) / f'peer{rank}.pt')
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_a_failed_rank_is_agreed_on_by_every_rank(tmp_path):
+    """one rank of a data-parallel group fails before its step's exchange (a malformed minibatch).  It
+    completes the step's collectives with the status word set; the healthy rank raises DataParallelPeerFailure at once instead
+    of sitting in the all-reduce until the communicator times out; no rank applies the step; the next step pairs up again and
+    leaves bit-identical replicas."""
+    port = 29500 + (os.getpid() % 2000) + 23
+    mp.spawn(_peer_failure_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (torch.load(tmp_path / f'peer{r}.pt') for r in range(2))
+    assert r0['kind'] == 'DataParallelPeerFailure' and 'peer rank' in r0['msg']
+    assert r1['kind'] == 'KeyError' and r1['agreed']
+    assert r0['same'] and r1['same']
+    assert r0['waited'] < 60 and r1['waited'] < 60
+    assert torch.equal(r0['w'], r1['w'])
