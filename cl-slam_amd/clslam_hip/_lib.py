@@ -28,7 +28,7 @@ class ConvDesc(C.Structure):
                 ('out_h', i32), ('out_w', i32), ('ch_out', i32),
                 ('ksize', i32), ('stride', i32), ('pad', i32), ('pad_mode', i32), ('upsample_a', i32),
                 ('act', i32), ('config', i32), ('actgrad_src', fptr), ('actgrad_kind', i32),
-                ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t), ('weight_wino', fptr)]
+                ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t), ('weight_wino', fptr), ('cu_limit', i32)]
 
 
 class TransposeItem(C.Structure):
@@ -138,7 +138,7 @@ _SIGNATURES = {
                                 fptr, C.c_void_p],
 }
 _RESTYPES = {'clslam_last_error': C.c_char_p, 'clslam_last_error_string': C.c_char_p, 'clslam_build_id': C.c_char_p}
-ABI_VERSION = 101          # include/clslam_hip.h CLSLAM_ABI_VERSION: struct layouts / pointer types this binding was written for
+ABI_VERSION = 102          # include/clslam_hip.h CLSLAM_ABI_VERSION: struct layouts / pointer types this binding was written for
 _SIZE_FNS = {'clslam_wino_weight_size': [i32, i32]}      # return size_t
 
 

@@ -216,6 +216,15 @@ class Engine:
         self.noise_draws = 0
         self.noise_stream = 0
         self.use_side_stream = os.environ.get('CLSLAM_SIDE_STREAM', '1') != '0'
+        # clslam_conv_desc.cu_limit of the persistent (stream-K / Winograd) conv launches.  The depth and the pose network of a
+        # step run on two streams; a persistent launch that takes every CU (140 KB of LDS each) shuts the other stream out
+        # for its whole duration.  With half of the chip per launch the two branches run side by side and every workgroup
+        # walks twice the units (the prologue / hand-off / epilogue phases of a launch are paid on half of the CUs).  Measured at
+        # 192x640 (profiles/r05_cu_limit_sweep.txt): minibatch of 3 / 5 / 9 triplets -2.7 / -2.9 / -1.8 % per step; 1 triplet
+        # +4 % (one triplet does not fill the chip: latency counts, not occupancy) and 33 triplets +3.7 % (every launch is long
+        # enough to fill it alone) -- hence the band.  CLSLAM_CU_LIMIT=<n> forces a value (0: the whole chip).
+        self.cu_limit_env = os.environ.get('CLSLAM_CU_LIMIT')
+        self.device_cus = (torch.cuda.get_device_properties(device).multi_processor_count if device.type == 'cuda' else 256)
         # steps 2..S of adapt(steps=S) keep the frozen encoders' features (see forward)
         self.reuse_frozen_features = os.environ.get('CLSLAM_REUSE_FROZEN', '1') != '0'
         # Winograd F(2x2,3x3) for the frozen encoders' 3x3 stride-1 convolutions (CLSLAM_NO_WINOGRAD=1: the direct kernels)
@@ -256,6 +265,11 @@ class Engine:
     def _use_tail(self) -> bool:
         return (self.async_tail and self.tail_stream is not None and self.device.type == 'cuda' and not self._capturing
                 and ops.PROFILE is None)
+
+    def cu_limit(self, B: int) -> int:
+        if self.cu_limit_env is not None:
+            return int(self.cu_limit_env)
+        return self.device_cus // 2 if (self.use_side_stream and 2 <= B <= 16) else 0
 
     def wait_training(self, stream=None) -> None:
         """Make `stream` (default: the current one) wait for the training step in flight: the optimizer step on the tail
@@ -630,6 +644,7 @@ class Engine:
         aug = {f: self._img(inputs['rgb_aug', f, 0]) for f in (-1, 0, 1)}
         rgb = {f: self._img(inputs['rgb', f, 0]) for f in (-1, 0, 1)}
         B = aug[0].shape[0]
+        ops.PERSISTENT_CU_LIMIT = self.cu_limit(B)
         # the kernels index with the engine's resolution: refuse anything else up front
         for name, group in (('rgb_aug', aug), ('rgb', rgb)):
             for f, t in group.items():
@@ -948,6 +963,7 @@ class Engine:
         allreduce: data-parallel mode -- callable(slice of the gradient arena) that sum-all-reduces it over the ranks on
         torch's current stream.  With it (and grad_buckets > 1) backward() exchanges the gradients itself, bucket by bucket
         (see __init__); self.grads_synced tells the caller so."""
+        ops.PERSISTENT_CU_LIMIT = self.cu_limit(B)
         ws = self._ws[B]
         t = ws.train
         c = ws.ctx
@@ -1374,6 +1390,7 @@ class Engine:
         """models['depth_decoder'](features) (dpp.py:931-936 calls it on the encoder's five features; networks/depth_decoder.py:
         51-71): {('disp', s): (N,1,H>>s,W>>s)} for s = 3..0 from the CURRENT decoder weights, by the same kernels as the step's
         forward.  Inference only: no graph is recorded and nothing of a training step in flight is touched."""
+        ops.PERSISTENT_CU_LIMIT = 0
         self.pack_if_needed()
         self._conv_workspace()
         self.wait_training()
@@ -1403,6 +1420,7 @@ class Engine:
     def run_pose_decoder(self, last_features):
         """models['pose_decoder']([features]) (dpp.py:957-965; networks/pose_decoder.py:37-54): (axis_angle, translation), each
         (N, 2, 1, 3), from the last feature map of ONE pose-encoder pass."""
+        ops.PERSISTENT_CU_LIMIT = 0
         if len(last_features) != 1:
             raise ClslamError('pose_decoder: the MI355X-native path implements num_input_features = 1')
         self.pack_if_needed()

@@ -127,9 +127,13 @@ def set_conv_workspace(stream_handle: int, workspace: Optional[torch.Tensor]) ->
         _CONV_WORKSPACES[stream_handle] = workspace
 
 
+# clslam_conv_desc.cu_limit of the conv launches that follow (0 = the whole chip): set by the engine per step, see there
+PERSISTENT_CU_LIMIT = 0
+
+
 def conv2d(src_a, weight, out, *, src_b=None, scale=None, shift=None, residual=None, ksize=3, stride=1,
            pad=None, pad_mode=PAD_ZERO, upsample_a=False, act=ACT_NONE, config=-1, actgrad_src=None,
-           actgrad_kind=ACT_NONE, workspace=None, weight_wino=None):
+           actgrad_kind=ACT_NONE, workspace=None, weight_wino=None, cu_limit=None):
     """src_a (B,Ha,Wa,Ca) NHWC; weight (Cout, k*k, Ca+Cb); out (B,Ho,Wo,Cout); weight_wino: wino_weight_transform(weight)."""
     B, Ho, Wo, Cout = out.shape
     Ha, Wa, Ca = src_a.shape[1:]
@@ -144,7 +148,8 @@ def conv2d(src_a, weight, out, *, src_b=None, scale=None, shift=None, residual=N
     d = _lib.ConvDesc(_p(src_a), _p(src_b), _p(weight), _p(scale), _p(shift), _p(residual), _p(out),
                       B, Hi, Wi, Ca, Cb, Ho, Wo, Cout, ksize, stride, pad, pad_mode, int(upsample_a), act, config,
                       _p(actgrad_src), actgrad_kind, None if workspace is None else workspace.data_ptr(),
-                      0 if workspace is None else workspace.numel(), _p(weight_wino))
+                      0 if workspace is None else workspace.numel(), _p(weight_wino),
+                      PERSISTENT_CU_LIMIT if cu_limit is None else cu_limit)
     if PROFILE is not None:     # armed by profile_begin(): the library timestamps the launch itself
         cfg = config if config >= 0 else _lib.get_lib().cdll.clslam_conv2d_pick_config(C.byref(d))
         # algorithmic bytes: every operand once (source a as stored, i.e. before the nearest-2x upsampling)
@@ -165,7 +170,7 @@ def conv_desc(src_a, out_shape, *, src_b=None, ksize=3, stride=1, pad=None, pad_
     if pad is None:
         pad = ksize // 2
     return _lib.ConvDesc(_p(src_a), _p(src_b), None, None, None, None, None, B, Hi, Wi, Ca, Cb, Ho, Wo, Cout,
-                         ksize, stride, pad, pad_mode, int(upsample_a), ACT_NONE, -1, None, ACT_NONE, None, 0, None)
+                         ksize, stride, pad, pad_mode, int(upsample_a), ACT_NONE, -1, None, ACT_NONE, None, 0, None, 0)
 
 
 def wino_weight_transform(w, out=None):

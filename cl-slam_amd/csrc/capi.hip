@@ -76,7 +76,8 @@ extern "C" int clslam_conv_profile_end(float* ms, int capacity, int* count) {
 }
 
 // 101: clslam_conv_desc grew `weight_wino` (appended), double dp_partial in the loss backward entry points
-extern "C" int clslam_version(void) { return 101; }
+// 102: clslam_conv_desc grew `cu_limit` (appended)
+extern "C" int clslam_version(void) { return 102; }
 // identity of the kernel sources this library was LINKED from (csrc/build.py passes it when it compiles this file, which it
 // does whenever any object is rebuilt): read from the loaded library, not from a file beside it
 #ifndef CLSLAM_BUILD_ID

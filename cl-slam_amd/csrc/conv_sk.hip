@@ -477,7 +477,7 @@ static int launch_sk(SkK k, const clslam_conv_desc* d, hipStream_t stream) {
     constexpr size_t lds_bytes = (size_t)2 * (PPs + 9 * BN) * 64 + 16;
     constexpr int per_cu = (int)std::max<size_t>(1, std::min<size_t>((size_t)(163840 / lds_bytes), (size_t)(2048 / (NWM * NWN * 64))));
     // (every workgroup must be co-resident: a consumer spins on lower-indexed producers; per_cu is the LDS / thread limit)
-    int G = sk_device_cus() * per_cu;
+    int G = (d->cu_limit > 0 ? std::min(d->cu_limit, sk_device_cus()) : sk_device_cus()) * per_cu;
     if (const char* e = getenv("CLSLAM_SK_GROUPS")) G = std::max(1, atoi(e));
     G = (int)std::min<long long>(std::min(G, kSkMaxGroups), k.units);
     k.G = G;

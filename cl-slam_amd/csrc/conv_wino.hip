@@ -488,12 +488,27 @@ int conv3x3_wino_supported(const clslam_conv_desc* d) {
 // hand-off per workgroup, ~7500 cycles per finish() -- are ~20-30 us; a stage costs ~3 us.  Measured on MI355X (tools/bench_conv.py,
 // profiles/r05_wino_microbench.txt): >= 8 units per workgroup (the pose encoder's 2B images, every K >= 8 / 384x1280 workload)
 // 93-110 TFLOP/s against 67-89 for the direct kernels; ~5 units (the depth encoder at B = 5) 55-63 against 67-80.
+// Workgroups of a launch: one per CU the descriptor grants it (clslam_conv_desc.cu_limit; CLSLAM_WINO_GROUPS / CLSLAM_SK_GROUPS
+// override it for experiments).
+static int wino_groups(const clslam_conv_desc* d) {
+    static const int forced = [] {
+        int v = 0;
+        if (const char* e = getenv("CLSLAM_SK_GROUPS")) v = std::max(1, atoi(e));
+        if (const char* e = getenv("CLSLAM_WINO_GROUPS")) v = std::max(1, atoi(e));
+        return v;
+    }();
+    int g = sk_device_cus();
+    if (d->cu_limit > 0) g = std::min(g, d->cu_limit);
+    if (forced) g = forced;
+    return std::min(g, kWinoMaxGroups);
+}
+
 int conv3x3_wino_units_per_group(const clslam_conv_desc* d) {
     int RB = 1, RH = 1, RW = 1;
     wino_pick_region(d->batch, d->out_h, d->out_w, RB, RH, RW);
     const long long tiles = (long long)cdiv(d->batch, RB) * cdiv((d->out_h + 1) / 2, RH) * cdiv((d->out_w + 1) / 2, RW) * cdiv(d->ch_out, 64);
     const long long units = tiles * (d->ch_a / 8);
-    return (int)(units / std::max(1, sk_device_cus()));
+    return (int)(units / std::max(1, wino_groups(d)));
 }
 
 // Called by clslam_conv2d for config 40.
@@ -514,9 +529,7 @@ int conv3x3_wino_dispatch(const clslam_conv_desc* d, hipStream_t stream) {
     k.units = (long long)k.tiles * k.NS;
     k.b_fastest = ((size_t)k.Cout * 16 * k.Cin > (size_t)k.B * k.Hi * k.Wi * k.Cin) ? 1 : 0;
     if (const char* e = getenv("CLSLAM_SK_B_FASTEST")) k.b_fastest = atoi(e);
-    int G = sk_device_cus();
-    if (const char* e = getenv("CLSLAM_SK_GROUPS")) G = std::max(1, atoi(e));
-    G = (int)std::min<long long>(std::min(G, kWinoMaxGroups), k.units);
+    const int G = (int)std::min<long long>(wino_groups(d), k.units);
     k.G = G;
     const size_t need = (size_t)kWinoSlabOffsetBytes + (size_t)G * kWinoSlabFloats * sizeof(float) + (CLSLAM_WINO_TRACE ? (size_t)G * 64 * 8 : 0);
     if (!d->workspace || d->workspace_bytes < need) {

@@ -39,8 +39,9 @@ extern "C" {
 
 /* Library identification / error text (thread-local). */
 /* ABI version: 101 = clslam_conv_desc.weight_wino appended, clslam_wino_weight_*; 100 -> 101 also covers the double* dp_partial of
- * clslam_warp_bwd / clslam_pose_bwd / clslam_loss_bwd*_pyramid (round 4).  Bindings check it before the first call.          */
-#define CLSLAM_ABI_VERSION 101
+ * clslam_warp_bwd / clslam_pose_bwd / clslam_loss_bwd*_pyramid (round 4); 102 = clslam_conv_desc.cu_limit appended.
+ * Bindings check it before the first call.                                                                                    */
+#define CLSLAM_ABI_VERSION 102
 int clslam_version(void);
 const char* clslam_last_error(void);
 const char* clslam_last_error_string(void); /* = clslam_last_error (the name SURVEY.md 8b lists) */
@@ -88,6 +89,13 @@ typedef struct clslam_conv_desc {
      * clslam_wino_weight_transform (3x3, stride 1, zero padding, one source; needs `workspace`).  NULL: the direct kernels.
      * Frozen weights (the two ResNet encoders) are transformed once per load; `weight` must still be set.              */
     const float* weight_wino;
+    /* Optional (ABI version >= 102): how many compute units a PERSISTENT launch (the stream-K and Winograd kernels: one or two
+     * resident workgroups per CU that walk the whole layer) may occupy; 0 = all of them.  A caller that runs independent
+     * branches on several streams (the depth and the pose network of one step) gives each launch half of the chip: two such
+     * launches then run side by side, each workgroup walks twice the units and the per-launch prologue / hand-off / epilogue
+     * phases cost half.  Measured on MI355X at 192x640: -2.9 % per step at 5 triplets, +3.7 % at 33.  Results
+     * do not depend on it beyond the summation order of the hand-off (fixed per (shape, cu_limit)).                       */
+    int32_t cu_limit;
 } clslam_conv_desc;
 int clslam_conv2d(const clslam_conv_desc* desc, void* stream);
 /* the tile configuration clslam_conv2d uses for desc->config < 0 (profiling / reporting) */

@@ -61,7 +61,7 @@ def test_binding_checks_the_abi_version():
     assert lib.cdll.clslam_version() == declared
     assert lib.cdll.clslam_last_error_string() == lib.cdll.clslam_last_error()
     import ctypes as C
-    assert C.sizeof(_lib.ConvDesc) == 7 * 8 + 15 * 4 + 4 + 8 + 4 + 4 + 8 + 8 + 8      # ... + weight_wino (appended)
+    assert C.sizeof(_lib.ConvDesc) == 7 * 8 + 15 * 4 + 4 + 8 + 4 + 4 + 8 + 8 + 8 + 4 + 4      # ... + weight_wino + cu_limit (+ tail padding)
     old = _lib.ABI_VERSION
     try:
         _lib.ABI_VERSION = old + 1
