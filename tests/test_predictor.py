@@ -159,7 +159,10 @@ def test_adapt_matches_reference_golden(backend, case, B, steps):
             for name, e_free, e_sel, norm, e_all, e_hip64, e_o64, e_bwd, e_bwd_t32, e_bwd_p, e_bwd_p_t32 in r['rows']:
                 # same decisions: rounding of the two fp32 forwards, amplified (<= 2e-3); at the kernel path's forward point the
                 # backward arithmetic alone: 2e-4 (tests/test_backward_parity.py has the whole ladder)
-                assert e_all < 2e-3 and e_bwd < 3e-4, (name, e_free, e_sel, e_all, e_bwd)
+                # (a 1-element bias gradient of norm 2e-5 is the residue of a cancelling sum: where the forward point falls
+                # decides its conditioning -- with the persistent launches on half of the chip torch's own fp32 autograd at the SAME
+                # point is 3.05e-4 from float64 on dispconv_3.bias; so: 3e-4, or 1.5x torch's fp32 there)
+                assert e_all < 2e-3 and e_bwd < max(3e-4, 1.5 * e_bwd_t32), (name, e_free, e_sel, e_all, e_bwd, e_bwd_t32)
         # adapted weights vs the reference's, in units of the learning rate (golden holds the first
         # 96 entries of every trainable tensor): at most a few percent may differ by a flipped update
         import math as _m
