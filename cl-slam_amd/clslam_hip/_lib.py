@@ -128,6 +128,8 @@ _SIGNATURES = {
                          fptr, C.c_void_p],
     'clslam_disp_grad': [fptr, fptr, fptr, i32, fptr, i32, i32, i32, i32, i32, C.c_void_p],
     'clslam_copy_multi': [C.c_void_p, i32, C.c_void_p],
+    'clslam_handoff_arm': [C.c_void_p],
+    'clslam_handoff_wait': [C.c_void_p, C.c_void_p, C.c_void_p],
     'clslam_conv_profile_begin': [i32],
     'clslam_conv_profile_end': [C.c_void_p, i32, C.c_void_p],
     'clslam_ip_scores': [fptr, fptr, fptr, i32, i32, i32, C.c_void_p],
@@ -138,8 +140,10 @@ _SIGNATURES = {
                                 fptr, C.c_void_p],
 }
 _RESTYPES = {'clslam_last_error': C.c_char_p, 'clslam_last_error_string': C.c_char_p, 'clslam_build_id': C.c_char_p}
-ABI_VERSION = 102          # include/clslam_hip.h CLSLAM_ABI_VERSION: struct layouts / pointer types this binding was written for
+ABI_VERSION = 103          # include/clslam_hip.h CLSLAM_ABI_VERSION: struct layouts / pointer types this binding was written for
 _SIZE_FNS = {'clslam_wino_weight_size': [i32, i32]}      # return size_t
+_PTR_FNS = {'clslam_handoff_event_create': []}             # return void*
+_VOID_FNS = {'clslam_handoff_event_destroy': [C.c_void_p]}
 
 
 class ClslamError(RuntimeError):
@@ -160,6 +164,12 @@ class Library:
         for name, argtypes in _SIZE_FNS.items():
             fn = getattr(self.cdll, name)
             fn.restype, fn.argtypes = C.c_size_t, argtypes
+        for name, argtypes in _PTR_FNS.items():
+            fn = getattr(self.cdll, name)
+            fn.restype, fn.argtypes = C.c_void_p, argtypes
+        for name, argtypes in _VOID_FNS.items():
+            fn = getattr(self.cdll, name)
+            fn.restype, fn.argtypes = None, argtypes
         for name, argtypes in _SIGNATURES.items():
             fn = getattr(self.cdll, name)  # AttributeError if the symbol is not exported
             fn.argtypes = argtypes
@@ -200,7 +210,7 @@ def install_library_for_tests(path) -> Library:
 
 
 def exported_symbols():
-    return list(_RESTYPES) + list(_SIZE_FNS) + list(_SIGNATURES)
+    return list(_RESTYPES) + list(_SIZE_FNS) + list(_PTR_FNS) + list(_VOID_FNS) + list(_SIGNATURES)
 
 
 def build_id() -> str:

@@ -216,6 +216,11 @@ class Engine:
         self.noise_draws = 0
         self.noise_stream = 0
         self.use_side_stream = os.environ.get('CLSLAM_SIDE_STREAM', '1') != '0'
+        # Releasing a side stream behind a launch of the dependency chain: torch.cuda.Event().record(main) puts a marker packet
+        # between two kernels of the chain (+5.0 us on the producer per hand-off, ~17 per step); an event that is the producing
+        # launch's own completion signal costs +1.3 us (tools/micro/event_gap.hip, profiles/r05_micro_calibration.txt).
+        # CLSLAM_HANDOFF=0: the recorded events of rounds 1-4.
+        self._handoff = (ops.Handoff() if (device.type == 'cuda' and os.environ.get('CLSLAM_HANDOFF', '1') != '0') else None)
         # clslam_conv_desc.cu_limit of the persistent (stream-K / Winograd) conv launches.  The depth and the pose network of a
         # step run on two streams; a persistent launch that takes every CU (140 KB of LDS each) shuts the other stream out
         # for its whole duration.  With half of the chip per launch the two branches run side by side and every workgroup
@@ -266,9 +271,16 @@ class Engine:
         return (self.async_tail and self.tail_stream is not None and self.device.type == 'cuda' and not self._capturing
                 and ops.PROFILE is None)
 
-    def cu_limit(self, B: int) -> int:
+    def cu_limit(self, B: int, phase: str = 'forward') -> int:
+        """phase: 'forward' (both encoders in flight), 'reuse' (steps 2..S of adapt(steps=S): decoders only -- nothing runs
+        beside the depth decoder's launches, they take the whole chip), 'backward'"""
+        env = os.environ.get('CLSLAM_CU_LIMIT_' + phase.upper())       # experiments
+        if env is not None:
+            return int(env)
         if self.cu_limit_env is not None:
             return int(self.cu_limit_env)
+        if phase == 'reuse':
+            return 0
         return self.device_cus // 2 if (self.use_side_stream and 2 <= B <= 16) else 0
 
     def wait_training(self, stream=None) -> None:
@@ -585,15 +597,22 @@ class Engine:
             skip = feats[i - 1] if i > 0 else None
             cin1 = NUM_CH_DEC[i] + (NUM_CH_ENC[i - 1] if i > 0 else 0)
             w, b = self._wb(f'depth_decoder/upconv_{i}_1.conv.conv', NUM_CH_DEC[i], cin1, 9)
+            fork = leaf is not None and 0 < i <= 3
+            ho = self._handoff if (fork and not self._capturing and ops.PROFILE is None) else None
+            if ho is not None:
+                ho.arm()          # the leaf stream is released by this convolution's own completion signal
             ops.conv2d(ws.x[i, 0], w, ws.x[i, 1], src_b=skip, shift=b, ksize=3, pad_mode=PAD_REFLECT, upsample_a=True,
                        act=ACT_ELU)
             x = ws.x[i, 1]
             if i <= 3:
                 w, b = self._wb(f'depth_decoder/dispconv_{i}.conv', 1, NUM_CH_DEC[i], 9)
-                if leaf is not None and i > 0:
-                    ev = torch.cuda.Event()
-                    ev.record(main)
-                    leaf.wait_event(ev)
+                if fork:
+                    if ho is not None:
+                        ho.release(main, leaf)
+                    else:
+                        ev = torch.cuda.Event()
+                        ev.record(main)
+                        leaf.wait_event(ev)
                     with self._on(leaf):
                         ops.dispconv_fwd(x, w.view(9, NUM_CH_DEC[i]), b, ws.disp[i])
                     forked = True
@@ -659,6 +678,8 @@ class Engine:
                 raise ClslamError(f'{k} must be ({B}, 4, 4), got {tuple(inputs[k].shape)}')
         ws = self.workspace(B)
         reuse = bool(reuse_frozen and self.reuse_frozen_features and getattr(ws, 'frozen_valid', False))
+        if reuse:
+            ops.PERSISTENT_CU_LIMIT = self.cu_limit(B, 'reuse')
         ws.frozen_valid = False
         memo_feats = self._memo_lookup(aug[0]) if (B == 1 and not reuse) else None
         if train:
@@ -963,7 +984,7 @@ class Engine:
         allreduce: data-parallel mode -- callable(slice of the gradient arena) that sum-all-reduces it over the ranks on
         torch's current stream.  With it (and grad_buckets > 1) backward() exchanges the gradients itself, bucket by bucket
         (see __init__); self.grads_synced tells the caller so."""
-        ops.PERSISTENT_CU_LIMIT = self.cu_limit(B)
+        ops.PERSISTENT_CU_LIMIT = self.cu_limit(B, 'backward')
         ws = self._ws[B]
         t = ws.train
         c = ws.ctx
@@ -1111,16 +1132,24 @@ class Engine:
         wg_streams = [wg] if (wg is None or self.side_stream is None) else [wg, self.side_stream]
         counter = [0]
 
-        def on_wg(fn):
-            """run fn on a wgrad stream after everything enqueued so far on the main stream"""
+        ho = self._handoff if (wg is not None and not self._capturing and ops.PROFILE is None) else None
+
+        def on_wg(fn, dep='record'):
+            """run fn on a wgrad stream.  dep: 'record' -- after everything enqueued so far on the main stream (an event
+            recorded there); 'armed' -- after the launch that took the hand-off event armed just before it (no marker packet on
+            the chain); None -- its inputs were complete before this function started (both wgrad streams are ordered behind
+            the loss backward by then)"""
             if wg is None:
                 fn()
                 return
             st = wg_streams[counter[0] % len(wg_streams)]
             counter[0] += 1
-            ev = torch.cuda.Event()
-            ev.record(main)
-            st.wait_event(ev)
+            if dep == 'armed':
+                ho.release(main, st)
+            elif dep == 'record':
+                ev = torch.cuda.Event()
+                ev.record(main)
+                st.wait_event(ev)
             with self._on(st):
                 fn()
 
@@ -1142,8 +1171,11 @@ class Engine:
                         t.items.append((t.disp_part[i], self._slot(self._g, f'depth_decoder/dispconv_{i}.conv.weight', 9 * ci + 1),
                                         9 * ci + 1, nb))
                     ops.dispconv_wgrad(t.dz_disp[i], ws.x[i, 1], t.disp_part[i])
-                on_wg(disp_wgrad)
+                # (reads dz_disp[i] -- the loss backward -- and the forward activation x[i,1] only)
+                on_wg(disp_wgrad, dep=None if ho is not None else 'record')
             nb1 = ops.fold_blocks(B, hi, wi, ci, False)
+            if ho is not None:
+                ho.arm()
             ops.fold_act_grad(dxp_in, ws.x[i, 1], t.dz[i, 1], h=hi, w=wi, ch=ci, border=1, pool=False, act=ACT_ELU,
                               bias_partial=t.bias_part[i, 1], disp_dz=t.dz_disp[i] if wd is not None else None,
                               disp_w=wd.view(9, ci) if wd is not None else None)
@@ -1152,11 +1184,14 @@ class Engine:
             cin1 = ci + (NUM_CH_ENC[i - 1] if i > 0 else 0)
             on_wg(lambda i=i, hi=hi, wi=wi, ci=ci, skip=skip, cin1=cin1, nb1=nb1: self._wgrad(
                 t, (ws.x[i, 0], skip), (B, hi, wi, ci), t.dz[i, 1], f'depth_decoder/upconv_{i}_1.conv.conv', ci, cin1, 9,
-                bias_blocks=nb1, bias_partial=t.bias_part[i, 1], pad_mode=PAD_REFLECT, upsample_a=True))
+                bias_blocks=nb1, bias_partial=t.bias_part[i, 1], pad_mode=PAD_REFLECT, upsample_a=True),
+                dep='armed' if ho is not None else 'record')
             wt = t.wt_dec[i, 1]
             dxa = t.dxp[1][:B * (hi + 2) * (wi + 2) * ci].view(B, hi + 2, wi + 2, ci)
             ops.conv2d(t.dz[i, 1], wt, dxa, ksize=3, pad=2)
             nb0 = ops.fold_blocks(B, hi, wi, ci, True)
+            if ho is not None:
+                ho.arm()
             ops.fold_act_grad(dxa, ws.x[i, 0], t.dz[i, 0], h=hi, w=wi, ch=ci, border=1, pool=True, act=ACT_ELU,
                               bias_partial=t.bias_part[i, 0])
             # upconv_i_0: input = x[i+1,1] (or the frozen encoder feature for i == 4)
@@ -1165,7 +1200,8 @@ class Engine:
             h2, w2 = hi >> 1, wi >> 1
             on_wg(lambda i=i, h2=h2, w2=w2, ci=ci, src=src, cin0=cin0, nb0=nb0: self._wgrad(
                 t, (src, None), (B, h2, w2, ci), t.dz[i, 0], f'depth_decoder/upconv_{i}_0.conv.conv', ci, cin0, 9,
-                bias_blocks=nb0, bias_partial=t.bias_part[i, 0], pad_mode=PAD_REFLECT))
+                bias_blocks=nb0, bias_partial=t.bias_part[i, 0], pad_mode=PAD_REFLECT),
+                dep='armed' if ho is not None else 'record')
             if i < 4:
                 wt = t.wt_dec[i, 0]
                 dxp_in = t.dxp[0][:B * (h2 + 2) * (w2 + 2) * cin0].view(B, h2 + 2, w2 + 2, cin0)

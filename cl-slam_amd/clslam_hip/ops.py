@@ -113,6 +113,49 @@ def _pa(t: Optional[torch.Tensor], dtype):
     return t.data_ptr()
 
 
+class Handoff:
+    """Releases a consumer stream behind ONE launch of a producer stream without a marker packet on the producer
+    (clslam_handoff_*, include/clslam_hip.h): `arm()` right before the producing conv2d() / fold_act_grad() call, `release(producer,
+    consumer)` after it.  A pool of events, re-used round-robin (an event may be re-armed once it has been waited on; the pool is
+    much larger than the hand-offs in flight).  On the emulator (one stream) both calls are no-ops."""
+    POOL = 64
+
+    def __init__(self) -> None:
+        self.lib = _lib.get_lib()
+        self.events = []
+        self.next = 0
+        self.armed = None
+
+    def arm(self) -> None:
+        if not self.lib.is_device:
+            return
+        if len(self.events) < self.POOL:
+            ev = self.lib.cdll.clslam_handoff_event_create()
+            if not ev:
+                raise _lib.ClslamError('clslam_handoff_event_create failed: ' + self.lib.cdll.clslam_last_error().decode())
+            self.events.append(ev)
+            self.armed = ev
+        else:
+            self.armed = self.events[self.next % self.POOL]
+        self.next += 1
+        self.lib.call('clslam_handoff_arm', self.armed)
+
+    def release(self, producer, consumer) -> None:
+        """`consumer` (torch.cuda.Stream) waits for the armed launch -- or, had none taken the event, for everything enqueued on
+        `producer` so far"""
+        ev, self.armed = self.armed, None
+        if ev is None:
+            return
+        self.lib.call('clslam_handoff_wait', ev, producer.cuda_stream, consumer.cuda_stream)
+
+    def __del__(self):
+        try:
+            for ev in self.events:
+                self.lib.cdll.clslam_handoff_event_destroy(ev)
+        except Exception:
+            pass
+
+
 # split-K scratch per stream (stream handle -> zero-initialised uint8 tensor), see clslam_conv_desc.workspace
 _CONV_WORKSPACES = {}
 

@@ -30,9 +30,24 @@ int check_launch(const char* what) {
 static thread_local std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof;
 static thread_local int g_prof_cap = 0;   // 0: not armed
 
+// the hand-off event armed by clslam_handoff_arm, waiting for the next launch that can carry it
+static thread_local hipEvent_t g_handoff = nullptr;
+
+hipEvent_t take_handoff_event() {
+    hipEvent_t e = g_handoff;
+    g_handoff = nullptr;
+    return e;
+}
+
 bool profile_next_events(hipEvent_t* start, hipEvent_t* stop) {
 #if CLSLAM_DEVICE_BUILD
-    if (g_prof_cap <= 0 || (int)g_prof.size() >= g_prof_cap) return false;
+    if (g_prof_cap <= 0 || (int)g_prof.size() >= g_prof_cap) {
+        // not measuring: an armed hand-off event rides on this launch as its completion signal (no start event)
+        hipEvent_t h = take_handoff_event();
+        if (h == nullptr) return false;
+        *start = nullptr; *stop = h;
+        return true;
+    }
     hipEvent_t a = nullptr, b = nullptr;
     if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return false;
     g_prof.emplace_back(a, b);
@@ -75,9 +90,60 @@ extern "C" int clslam_conv_profile_end(float* ms, int capacity, int* count) {
     return rc;
 }
 
+extern "C" void* clslam_handoff_event_create(void) {
+#if CLSLAM_DEVICE_BUILD
+    hipEvent_t e = nullptr;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+        clslam::set_error("handoff_event_create: %s", hipGetErrorString(hipGetLastError()));
+        return nullptr;
+    }
+    return (void*)e;
+#else
+    return nullptr;      // the emulator has one stream: nothing to hand off
+#endif
+}
+
+extern "C" void clslam_handoff_event_destroy(void* event) {
+#if CLSLAM_DEVICE_BUILD
+    if (event) (void)hipEventDestroy((hipEvent_t)event);
+#else
+    (void)event;
+#endif
+}
+
+extern "C" int clslam_handoff_arm(void* event) {
+    CLSLAM_REQUIRE(event, "handoff_arm: null event");
+    CLSLAM_REQUIRE(clslam::g_handoff == nullptr, "handoff_arm: an armed event has not been waited on (clslam_handoff_wait)");
+    clslam::g_handoff = (hipEvent_t)event;
+    return CLSLAM_OK;
+}
+
+extern "C" int clslam_handoff_wait(void* event, void* producer_stream, void* consumer_stream) {
+    CLSLAM_REQUIRE(event, "handoff_wait: null event");
+#if CLSLAM_DEVICE_BUILD
+    hipEvent_t e = (hipEvent_t)event;
+    if (clslam::g_handoff == e) {       // nothing launched since the arm call could carry it: an ordinary record
+        clslam::g_handoff = nullptr;
+        if (hipEventRecord(e, (hipStream_t)producer_stream) != hipSuccess) {
+            clslam::set_error("handoff_wait: hipEventRecord: %s", hipGetErrorString(hipGetLastError()));
+            return CLSLAM_ERR_LAUNCH;
+        }
+    }
+    if (hipStreamWaitEvent((hipStream_t)consumer_stream, e, 0) != hipSuccess) {
+        clslam::set_error("handoff_wait: hipStreamWaitEvent: %s", hipGetErrorString(hipGetLastError()));
+        return CLSLAM_ERR_LAUNCH;
+    }
+#else
+    (void)producer_stream; (void)consumer_stream;
+    if (clslam::g_handoff == (hipEvent_t)event) clslam::g_handoff = nullptr;
+#endif
+    return CLSLAM_OK;
+}
+
 // 101: clslam_conv_desc grew `weight_wino` (appended), double dp_partial in the loss backward entry points
 // 102: clslam_conv_desc grew `cu_limit` (appended)
-extern "C" int clslam_version(void) { return 102; }
+// 103: clslam_handoff_* (additive)
+extern "C" int clslam_version(void) { return 103; }
 // identity of the kernel sources this library was LINKED from (csrc/build.py passes it when it compiles this file, which it
 // does whenever any object is rebuilt): read from the loaded library, not from a file beside it
 #ifndef CLSLAM_BUILD_ID

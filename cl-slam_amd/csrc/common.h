@@ -59,7 +59,10 @@ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 // Measurement hook (clslam_conv_profile_begin/end, bench.py's roofline leg): while armed, every conv launch of
 // this host thread carries its own start/stop events, i.e. the kernel's execution time as rocprofv3 reports it
 // (an event pair recorded AROUND a launch also counts the dispatch gap, ~3 us).  False when not armed.
+// Also true (with *start == nullptr) when a hand-off event is armed (clslam_handoff_arm): the launch then carries it as its
+// completion signal.  take_handoff_event(): the same for launches that are never timed (nullptr: none armed).
 bool profile_next_events(hipEvent_t* start, hipEvent_t* stop);
+hipEvent_t take_handoff_event();
 
 template <typename F, typename Arg>
 inline void conv_launch(F kernel, int nblk, hipStream_t stream, const Arg& k) {

@@ -564,6 +564,13 @@ extern "C" int clslam_fold_act_grad(const float* dxp, const float* yout, float* 
     CLSLAM_REQUIRE(!bias_partial || (64 % (ch / 4) == 0), "fold_act_grad: fused bias sums need ch/4 to divide 64");
     CLSLAM_REQUIRE(total < ((size_t)1 << 31) - 256 * 4096, "fold_act_grad: tensor too large for 32-bit indexing");
     const int blocks = clslam_fold_blocks(batch, h, w, ch, pool);
+#if CLSLAM_DEVICE_BUILD
+    if (hipEvent_t done = take_handoff_event()) {      // the weight-gradient stream is released by this launch's own completion
+        hipExtLaunchKernelGGL(fold_act_grad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, nullptr, done, 0, dxp, yout, dz,
+                              bias_partial, batch, h, w, ch, border, pool, act, ch_stride, disp_dz, disp_w);
+        return check_launch("fold_act_grad");
+    }
+#endif
     hipLaunchKernelGGL(fold_act_grad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dxp, yout, dz, bias_partial, batch,
                        h, w, ch, border, pool, act, ch_stride, disp_dz, disp_w);
     return check_launch("fold_act_grad");

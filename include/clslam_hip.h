@@ -39,9 +39,9 @@ extern "C" {
 
 /* Library identification / error text (thread-local). */
 /* ABI version: 101 = clslam_conv_desc.weight_wino appended, clslam_wino_weight_*; 100 -> 101 also covers the double* dp_partial of
- * clslam_warp_bwd / clslam_pose_bwd / clslam_loss_bwd*_pyramid (round 4); 102 = clslam_conv_desc.cu_limit appended.
+ * clslam_warp_bwd / clslam_pose_bwd / clslam_loss_bwd*_pyramid (round 4); 102 = clslam_conv_desc.cu_limit appended; 103 = clslam_handoff_* added.
  * Bindings check it before the first call.                                                                                    */
-#define CLSLAM_ABI_VERSION 102
+#define CLSLAM_ABI_VERSION 103
 int clslam_version(void);
 const char* clslam_last_error(void);
 const char* clslam_last_error_string(void); /* = clslam_last_error (the name SURVEY.md 8b lists) */
@@ -338,6 +338,22 @@ int clslam_adam_step(float* param, const float* grad, float* exp_avg, float* exp
  * milliseconds in launch order (at most `capacity`), stores how many there were in *count and disarms.   */
 int clslam_conv_profile_begin(int max_launches);
 int clslam_conv_profile_end(float* ms, int capacity, int* count);
+
+/* ---------------------------------------------------------------------------------------------
+ * Cross-stream hand-off without a marker packet on the PRODUCER's stream (no reference counterpart: the reference
+ * has one stream).  The step's dependency chain (decoder forward, data-gradient chain of the backward) releases work to
+ * the side streams ~17 times per step; hipEventRecord() puts a barrier packet between two kernels of the chain every
+ * time (measured on MI355X / ROCm 7.2, tools/micro/event_gap.hip: +5.0 us per hand-off on the producer), while an event
+ * that IS the producing kernel's completion signal (hipExtLaunchKernel stopEvent) costs +1.3 us.
+ *   clslam_handoff_arm(ev):   the next clslam_conv2d / clslam_fold_act_grad launch of THIS host thread completes `ev`
+ *   clslam_handoff_wait(ev, producer, consumer):  `consumer` stream waits for `ev`; if no launch has taken the armed
+ *                             event since clslam_handoff_arm (an op that does not support it, an empty batch) it is
+ *                             recorded on `producer` first -- never a missing dependency.
+ * Events come from clslam_handoff_event_create (timing disabled) and may be re-armed once waited on.                 */
+void* clslam_handoff_event_create(void);
+void clslam_handoff_event_destroy(void* event);
+int clslam_handoff_arm(void* event);
+int clslam_handoff_wait(void* event, void* producer_stream, void* consumer_stream);
 
 /* ---------------------------------------------------------------------------------------------
  * nitems independent device-to-device copies in one launch (items is a HOST array; sizes in bytes,
