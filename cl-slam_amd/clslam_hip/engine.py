@@ -101,7 +101,9 @@ def _device_streams(device) -> Dict[str, Any]:
     key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
     pool = _STREAM_POOL.get(key)
     if pool is None:
-        pool = {name: torch.cuda.Stream(device=device) for name in ('main', 'side', 'wg', 'tail', 'capture')}
+        # CLSLAM_PRIO_<NAME> = -1 (high) / 0 / 1 (low): HIP queue priority of a stream (experiments, profiles/r05_stream_priority.txt)
+        pool = {name: torch.cuda.Stream(device=device, priority=int(os.environ.get('CLSLAM_PRIO_' + name.upper(), '0')))
+                for name in ('main', 'side', 'wg', 'tail', 'capture')}
         _STREAM_POOL[key] = pool
     return pool
 
@@ -229,6 +231,7 @@ class Engine:
         # +4 % (one triplet does not fill the chip: latency counts, not occupancy) and 33 triplets +3.7 % (every launch is long
         # enough to fill it alone) -- hence the band.  CLSLAM_CU_LIMIT=<n> forces a value (0: the whole chip).
         self.cu_limit_env = os.environ.get('CLSLAM_CU_LIMIT')
+        self._cu_enc = self._cu_dec = 0     # set per forward(); the stand-alone callables (run_encoder, ...) take the whole chip
         self.device_cus = (torch.cuda.get_device_properties(device).multi_processor_count if device.type == 'cuda' else 256)
         # steps 2..S of adapt(steps=S) keep the frozen encoders' features (see forward)
         self.reuse_frozen_features = os.environ.get('CLSLAM_REUSE_FROZEN', '1') != '0'
@@ -271,15 +274,16 @@ class Engine:
         return (self.async_tail and self.tail_stream is not None and self.device.type == 'cuda' and not self._capturing
                 and ops.PROFILE is None)
 
-    def cu_limit(self, B: int, phase: str = 'forward') -> int:
-        """phase: 'forward' (both encoders in flight), 'reuse' (steps 2..S of adapt(steps=S): decoders only -- nothing runs
-        beside the depth decoder's launches, they take the whole chip), 'backward'"""
+    def cu_limit(self, B: int, phase: str = 'encoders') -> int:
+        """phase: 'encoders' (the two frozen encoders side by side: half of the chip each), 'decoders', 'backward' (the whole
+        chip: in steps 2..S of adapt(steps=S) nothing runs beside the depth decoder's launches -- and the decoders' summation
+        order must not depend on whether the encoders ran, tests/test_frozen_reuse.py holds the reuse bitwise invisible)"""
         env = os.environ.get('CLSLAM_CU_LIMIT_' + phase.upper())       # experiments
         if env is not None:
             return int(env)
         if self.cu_limit_env is not None:
             return int(self.cu_limit_env)
-        if phase == 'reuse':
+        if phase != 'encoders':
             return 0
         return self.device_cus // 2 if (self.use_side_stream and 2 <= B <= 16) else 0
 
@@ -542,6 +546,7 @@ class Engine:
         input as the stage's first 3x3 convolution and nothing depends on them until its second one, but at 0.16-0.3 GF
         they are pure launch latency (~11 us each for ~1 us of MFMA work): on `aux` they run underneath conv1 instead of
         between conv1 and conv2 of the chain.  `stream`: the stream this encoder's launches go to (needed with aux)."""
+        ops.PERSISTENT_CU_LIMIT = self._cu_enc
         for i, (img_a, img_b, off, cnt) in enumerate(stem_inputs):
             if waits is not None:
                 (stream or torch.cuda.current_stream(self.device)).wait_event(waits[i])
@@ -585,6 +590,7 @@ class Engine:
 
     def _depth_decoder(self, ws, feats: List[torch.Tensor]) -> None:
         x = feats[4]
+        ops.PERSISTENT_CU_LIMIT = self._cu_dec
         # the disparity heads of scales 3..1 are leaves of the chain (only the view synthesis reads them): they go to
         # the wgrad stream, idle during the forward, instead of sitting between two convolutions of the chain
         main = self._main
@@ -622,6 +628,7 @@ class Engine:
             main.wait_stream(leaf)
 
     def _pose_decoder(self, ws, f4: torch.Tensor) -> None:
+        ops.PERSISTENT_CU_LIMIT = self._cu_dec
         w, b = self._wb('pose_decoder/squeeze', 256, 512, 1)
         ops.conv2d(f4, w, ws.sq, shift=b, ksize=1, pad=0, act=ACT_RELU)
         w, b = self._wb('pose_decoder/pose_0', 256, 256, 9)
@@ -663,7 +670,8 @@ class Engine:
         aug = {f: self._img(inputs['rgb_aug', f, 0]) for f in (-1, 0, 1)}
         rgb = {f: self._img(inputs['rgb', f, 0]) for f in (-1, 0, 1)}
         B = aug[0].shape[0]
-        ops.PERSISTENT_CU_LIMIT = self.cu_limit(B)
+        self._cu_enc, self._cu_dec = self.cu_limit(B, 'encoders'), self.cu_limit(B, 'decoders')
+        ops.PERSISTENT_CU_LIMIT = self._cu_dec
         # the kernels index with the engine's resolution: refuse anything else up front
         for name, group in (('rgb_aug', aug), ('rgb', rgb)):
             for f, t in group.items():
@@ -678,8 +686,6 @@ class Engine:
                 raise ClslamError(f'{k} must be ({B}, 4, 4), got {tuple(inputs[k].shape)}')
         ws = self.workspace(B)
         reuse = bool(reuse_frozen and self.reuse_frozen_features and getattr(ws, 'frozen_valid', False))
-        if reuse:
-            ops.PERSISTENT_CU_LIMIT = self.cu_limit(B, 'reuse')
         ws.frozen_valid = False
         memo_feats = self._memo_lookup(aug[0]) if (B == 1 and not reuse) else None
         if train:
@@ -1386,6 +1392,7 @@ class Engine:
             stem = [(x, None, 0, n)]
         else:
             stem = [(x[:, :3].contiguous(), x[:, 3:].contiguous(), 0, n)]
+        self._cu_enc = 0
         feats = self._encoder(self.enc[which], bufs, n, stem)
         self._memo = None
         if which == 'depth_encoder' and n == 1 and self.descriptor_memo:
@@ -1413,6 +1420,7 @@ class Engine:
             st = SimpleNamespace(penc=self._enc_bufs(n), sq=E(n, h5, w5, 256), p0=E(n, h5, w5, 256), p1=E(n, h5, w5, 256),
                                  pmean=E(n, 256), pose=E(n, 12))
             self._ws[key] = st
+        self._cu_enc = self._cu_dec = 0
         feats = self._encoder(self.enc['pose_encoder'], st.penc, n, [(a, b, 0, n)])
         self._pose_decoder(st, feats[4])
         return st.pose
@@ -1426,7 +1434,7 @@ class Engine:
         """models['depth_decoder'](features) (dpp.py:931-936 calls it on the encoder's five features; networks/depth_decoder.py:
         51-71): {('disp', s): (N,1,H>>s,W>>s)} for s = 3..0 from the CURRENT decoder weights, by the same kernels as the step's
         forward.  Inference only: no graph is recorded and nothing of a training step in flight is touched."""
-        ops.PERSISTENT_CU_LIMIT = 0
+        self._cu_dec = self.cu_limit(0, 'decoders')
         self.pack_if_needed()
         self._conv_workspace()
         self.wait_training()
@@ -1456,7 +1464,7 @@ class Engine:
     def run_pose_decoder(self, last_features):
         """models['pose_decoder']([features]) (dpp.py:957-965; networks/pose_decoder.py:37-54): (axis_angle, translation), each
         (N, 2, 1, 3), from the last feature map of ONE pose-encoder pass."""
-        ops.PERSISTENT_CU_LIMIT = 0
+        self._cu_dec = self.cu_limit(0, 'decoders')
         if len(last_features) != 1:
             raise ClslamError('pose_decoder: the MI355X-native path implements num_input_features = 1')
         self.pack_if_needed()
