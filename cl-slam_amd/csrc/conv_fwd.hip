@@ -21,6 +21,8 @@
 // consecutive k-steps (k = 4*(lane/MF)+t), so no operand shuffling is needed.
 #include "common.h"
 
+#include <type_traits>
+
 namespace clslam {
 
 struct ConvK {
@@ -191,29 +193,83 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvK p) {
     }
 
     // ---- epilogue: BN/bias, residual, activation, NHWC store (lanes run along channels) ------
+    // Straight-line phases (operands of all elements from clamped addresses, values with the activation switch outside the
+    // element loop, then the stores back to back): see conv_patch.hip -- the element-by-element form serialised every store
+    // behind an `s_waitcnt vmcnt(0)`.
+    auto element = [&](int i, int j, int r, bool& ok) -> size_t {
+        int row;
+        if constexpr (MF == 32) row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        else row = 4 * (lane >> 4) + r;
+        const int m = m0 + wm0 + i * MF + row;
+        const int n = n0 + wn0 + j * MF + (lane % MF);
+        ok = m < p.M && n < p.Cout;
+        return (size_t)min(m, p.M - 1) * p.Cout + min(n, p.Cout - 1);
+    };
+    float sc[TN], sh[TN];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+    for (int j = 0; j < TN; ++j) {
+        const int n = min(n0 + wn0 + j * MF + (lane % MF), p.Cout - 1);
+        sc[j] = p.scale ? p.scale[n] : 1.f;
+        sh[j] = p.shift ? p.shift[n] : 0.f;
+    }
+    float resq[TM][TN][NACC], agq[TM][TN][NACC];
+    const bool has_res = p.residual != nullptr, has_ag = p.actgrad_src != nullptr;
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n0 + wn0 + j * MF + (lane % MF);
-            if (n >= p.Cout) continue;
-            const float sc = p.scale ? p.scale[n] : 1.f;
-            const float sh = p.shift ? p.shift[n] : 0.f;
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < NACC; ++r) { resq[i][j][r] = 0.f; agq[i][j][r] = 1.f; }
+    if (has_res) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < NACC; ++r) { bool ok; resq[i][j][r] = p.residual[element(i, j, r, ok)]; }
+    }
+    if (has_ag) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < NACC; ++r) { bool ok; agq[i][j][r] = p.actgrad_src[element(i, j, r, ok)]; }
+    }
+    auto values = [&](auto act_tag) {
+        constexpr int ACT = decltype(act_tag)::value;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < NACC; ++r) {
+                    const float v = acc[i][j][r] * sc[j] + sh[j] + resq[i][j][r];
+                    acc[i][j][r] = ACT < 0 ? apply_act(v, p.act) : apply_act(v, ACT);
+                }
+    };
+    if (p.act == CLSLAM_ACT_RELU) values(std::integral_constant<int, CLSLAM_ACT_RELU>{});
+    else if (p.act == CLSLAM_ACT_NONE) values(std::integral_constant<int, CLSLAM_ACT_NONE>{});
+    else if (p.act == CLSLAM_ACT_ELU) values(std::integral_constant<int, CLSLAM_ACT_ELU>{});
+    else values(std::integral_constant<int, -1>{});
+    if (has_ag) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < NACC; ++r) acc[i][j][r] *= act_grad_from_output(agq[i][j][r], p.actgrad_kind);
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < NACC; ++r) {
-                int row;
-                if constexpr (MF == 32) row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                else row = 4 * (lane >> 4) + r;
-                const int m = m0 + wm0 + i * MF + row;
-                if (m >= p.M) continue;
-                float v = acc[i][j][r] * sc + sh;
-                if (p.residual) v += p.residual[(size_t)m * p.Cout + n];
-                v = apply_act(v, p.act);
-                if (p.actgrad_src) v *= act_grad_from_output(p.actgrad_src[(size_t)m * p.Cout + n], p.actgrad_kind);
-                p.out[(size_t)m * p.Cout + n] = v;
+                bool ok;
+                const size_t o = element(i, j, r, ok);
+                if (ok) p.out[o] = acc[i][j][r];
             }
-        }
-    }
 }
 
 template <int BM, int BN, int BK, int MF, int WGM>

@@ -15,6 +15,8 @@
 // enough to tile (forward, and dgrad on the padded domain with pad = 2).
 #include "common.h"
 
+#include <type_traits>
+
 namespace clslam {
 
 constexpr int kSplitKMaxTiles = 16384;   // counters at the head of the caller's workspace (64 KiB)
@@ -305,37 +307,94 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(PatchK p) {
     }
 
     // ---- epilogue --------------------------------------------------------------------------------
+    // Three straight-line phases: (1) the optional operands (residual, activation-gradient source) of ALL the lane's elements
+    // loaded back to back from clamped (always valid) addresses, (2) every value computed with the activation switch OUTSIDE the
+    // element loop, (3) all stores back to back.  The element-by-element form (load? - value - load? - store per element, the
+    // activation's branches in between) made hipcc put an `s_waitcnt vmcnt(0)` in front of every load and store: eight serial
+    // memory round trips per workgroup, ~5 us of its ~11 us life on the 16-channel layers (round 5).
+    constexpr int NE = TM * TN * NACC;
+    auto element = [&](int i, int j, int r, bool& ok) -> size_t {
+        int row;
+        if constexpr (MF == 32) row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        else row = 4 * (lane >> 4) + r;
+        const int m = wm0 + i * MF + row;
+        const int n = n0 + wn0 + j * MF + (lane % MF);
+        int oy, ox;
+        if constexpr (RUN) {
+            ok = (m0 + m < p.Ho * p.Wo) && n < p.Cout;
+            const int mm = min(m0 + m, p.Ho * p.Wo - 1);
+            oy = mm / p.Wo; ox = mm % p.Wo;
+        } else {
+            oy = oy0 + m / TW; ox = ox0 + m % TW;
+            ok = oy < p.Ho && ox < p.Wo && n < p.Cout;
+            oy = min(oy, p.Ho - 1); ox = min(ox, p.Wo - 1);
+        }
+        return (((size_t)b * p.Ho + oy) * p.Wo + ox) * p.Cout + min(n, p.Cout - 1);
+    };
+    float vals[TM][TN][NACC], resq[TM][TN][NACC], agq[TM][TN][NACC];
+    const bool has_res = !PRE_RES && p.residual != nullptr, has_ag = p.actgrad_src != nullptr;
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n0 + wn0 + j * MF + (lane % MF);
-            if (n >= p.Cout) continue;
-            const float sc = scv[j], sh = shv[j];
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < NACC; ++r) {
-                int row;
-                if constexpr (MF == 32) row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                else row = 4 * (lane >> 4) + r;
-                const int m = wm0 + i * MF + row;
-                int oy, ox;
-                if constexpr (RUN) {
-                    if (m0 + m >= p.Ho * p.Wo) continue;
-                    oy = (m0 + m) / p.Wo; ox = (m0 + m) % p.Wo;
-                } else {
-                    oy = oy0 + m / TW; ox = ox0 + m % TW;
-                    if (oy >= p.Ho || ox >= p.Wo) continue;
-                }
-                const size_t o = (((size_t)b * p.Ho + oy) * p.Wo + ox) * p.Cout + n;
-                float v = (NCH == 2 ? acc[i][j][0][r] + acc[i][j][NCH - 1][r] : acc[i][j][0][r]) * sc + sh;
-                if constexpr (PRE_RES) v += resv[r];
-                else if (p.residual) v += p.residual[o];
-                v = apply_act(v, p.act);
-                if (p.actgrad_src) v *= act_grad_from_output(p.actgrad_src[o], p.actgrad_kind);
-                p.out[o] = v;
+                if constexpr (PRE_RES) resq[i][j][r] = resv[r];
+                else resq[i][j][r] = 0.f;
+                agq[i][j][r] = 1.f;
             }
-        }
+    if (has_res) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < NACC; ++r) { bool ok; resq[i][j][r] = p.residual[element(i, j, r, ok)]; }
     }
+    if (has_ag) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < NACC; ++r) { bool ok; agq[i][j][r] = p.actgrad_src[element(i, j, r, ok)]; }
+    }
+    auto values = [&](auto act_tag) {
+        constexpr int ACT = decltype(act_tag)::value;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < NACC; ++r) {
+                    float v = (NCH == 2 ? acc[i][j][0][r] + acc[i][j][NCH - 1][r] : acc[i][j][0][r]) * scv[j] + shv[j];
+                    v += resq[i][j][r];
+                    vals[i][j][r] = ACT < 0 ? apply_act(v, p.act) : apply_act(v, ACT);
+                }
+    };
+    if (p.act == CLSLAM_ACT_ELU) values(std::integral_constant<int, CLSLAM_ACT_ELU>{});
+    else if (p.act == CLSLAM_ACT_RELU) values(std::integral_constant<int, CLSLAM_ACT_RELU>{});
+    else if (p.act == CLSLAM_ACT_NONE) values(std::integral_constant<int, CLSLAM_ACT_NONE>{});
+    else values(std::integral_constant<int, -1>{});
+    if (has_ag) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < NACC; ++r) vals[i][j][r] *= act_grad_from_output(agq[i][j][r], p.actgrad_kind);
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < NACC; ++r) {
+                bool ok;
+                const size_t o = element(i, j, r, ok);
+                if (ok) p.out[o] = vals[i][j][r];
+            }
+    (void)NE;
 }
 
 // SKOK: the configuration has a split-K instantiation (the small-M ones: 20-23)

@@ -105,18 +105,30 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
             acc[1] = mfma_32x32x2(a, b1, acc[1]);
         }
     }
+    // Epilogue in two straight-line phases: every value first (BN scale / shift of both channel halves loaded up front), then
+    // the 32 stores back to back.  With `load scale/shift -> (value, conditional store) x 16` per half hipcc put an
+    // `s_waitcnt vmcnt(0)` in front of EVERY store: 32 serial memory round trips per workgroup (round 5).
+    float sc[2], sh[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { sc[j] = scale[j * 32 + i]; sh[j] = shift[j * 32 + i]; }
+    // (the four loads are consumed HERE: hipcc sinks the value computation into the conditional store blocks otherwise and
+    // guards each of them with `s_waitcnt vmcnt(2)` -- which, stores counting in vmcnt, keeps at most two stores in flight)
+    consume_now(sc[0]); consume_now(sh[0]); consume_now(sc[1]); consume_now(sh[1]);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float v = acc[j][r] * sc[j] + sh[j];
+            acc[j][r] = v > 0.f ? v : 0.f;
+        }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int n = j * 32 + i;
-        const float sc = scale[n], sh = shift[n];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = (r & 3) + 8 * (r >> 2) + 4 * g;  // pixel index inside the wave's 32
             const int oy = oy0 + wave * 2 + (row >> 4), ox = ox0 + (row & 15);
-            if (oy < Ho && ox < Wo) {
-                const float v = acc[j][r] * sc + sh;
-                out[(((size_t)b * Ho + oy) * Wo + ox) * 64 + n] = v > 0.f ? v : 0.f;
-            }
+            if (oy < Ho && ox < Wo) out[(((size_t)b * Ho + oy) * Wo + ox) * 64 + n] = acc[j][r];
         }
     }
 }

@@ -86,6 +86,10 @@ __device__ __forceinline__ float coherent_load(const float* p) { return __hip_at
 __device__ __forceinline__ void coherent_store_u32(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ unsigned coherent_inc(unsigned* p) { return __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void stores_complete() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// The value is needed HERE as far as the compiler is concerned: the wait for its load is placed at this point instead of inside
+// every conditional block that uses it later (where, stores counting in vmcnt on gfx9, `s_waitcnt vmcnt(n)` throttles the
+// stores of an epilogue to n in flight).
+__device__ __forceinline__ void consume_now(float& v) { asm volatile("" : "+v"(v)); }
 
 __device__ __forceinline__ unsigned coherent_load_u32(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void spin_pause() { __builtin_amdgcn_s_sleep(8); }

@@ -79,6 +79,7 @@ inline float coherent_load(const float* p) { float v; __atomic_load(p, &v, __ATO
 inline void coherent_store_u32(unsigned* p, unsigned v) { __atomic_store_n(p, v, __ATOMIC_SEQ_CST); }
 inline unsigned coherent_inc(unsigned* p) { return __atomic_fetch_add(p, 1u, __ATOMIC_SEQ_CST); }
 inline void stores_complete() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+inline void consume_now(float&) {}
 
 inline unsigned coherent_load_u32(const unsigned* p) { return __atomic_load_n(p, __ATOMIC_SEQ_CST); }
 inline void spin_pause() { ::emu_yield_os(); }   // the producer block runs on another host thread

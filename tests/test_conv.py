@@ -280,3 +280,4 @@ def test_conv2d_winograd(backend, case, config, monkeypatch):
     assert int(ws[:65536].view(torch.int32).abs().sum()) == 0
     with pytest.raises(Exception, match='weight_wino'):
         ops.conv2d(t(x), t(w), out, ksize=3, pad=pad, config=config, workspace=ws)
+
