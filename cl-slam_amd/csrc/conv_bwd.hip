@@ -85,6 +85,10 @@ __global__ __launch_bounds__(256) void fold_act_grad_kernel(const float* __restr
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         const int ny = pool ? 2 : 1;
         const int Yf = pool ? 2 * y : y, Xf = pool ? 2 * x : x;
+        // the activation's output is requested together with the gradient taps below (it was a second, dependent round trip)
+        const size_t o = ((size_t)(b * Ho + y) * Wo + x) * C + c4 * 4;
+        float4 yv = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (yout) yv = *reinterpret_cast<const float4*>(yout + o);
         // Fast path (all but the two outermost rows / columns): every footprint pixel folds from exactly one
         // padded position, so the 1 (or 2x2) float4 loads and the 9 head-gradient taps are unconditional and in
         // flight together.  The general path below walks variable-length lists: one load, one wait at a time.
@@ -152,9 +156,7 @@ __global__ __launch_bounds__(256) void fold_act_grad_kernel(const float* __restr
                     }
             }
         }
-        const size_t o = ((size_t)(b * Ho + y) * Wo + x) * C + c4 * 4;
         if (yout) {
-            const float4 yv = *reinterpret_cast<const float4*>(yout + o);
             acc.x *= act_grad_from_output(yv.x, act);
             acc.y *= act_grad_from_output(yv.y, act);
             acc.z *= act_grad_from_output(yv.z, act);

@@ -142,16 +142,19 @@ __global__ void maxpool3x3s2_kernel(const float* __restrict__ in, float* __restr
         const int ox = (int)((idx / C4) % Wo);
         const int oy = (int)((idx / ((size_t)C4 * Wo)) % Ho);
         const int b = (int)(idx / ((size_t)C4 * Wo * Ho));
-        float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
-        for (int ky = 0; ky < 3; ++ky) {
-            const int iy = 2 * oy - 1 + ky;
-            if (iy < 0 || iy >= H) continue;
-            for (int kx = 0; kx < 3; ++kx) {
-                const int ix = 2 * ox - 1 + kx;
-                if (ix < 0 || ix >= W) continue;
-                const float4 v = *reinterpret_cast<const float4*>(in + (((size_t)b * H + iy) * W + ix) * C + c4 * 4);
-                m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
-            }
+        // Nine UNCONDITIONAL loads from clamped positions, all in flight together: a tap outside the image repeats one inside
+        // the window (the centre (2oy, 2ox) always is), which leaves the maximum unchanged.  With `continue` per tap every
+        // load sat in its own block behind an `s_waitcnt vmcnt(0)`: nine serial memory round trips per output (round 5).
+        float4 v[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int iy = min(max(2 * oy - 1 + t / 3, 0), H - 1), ix = min(max(2 * ox - 1 + t % 3, 0), W - 1);
+            v[t] = *reinterpret_cast<const float4*>(in + (((size_t)b * H + iy) * W + ix) * C + c4 * 4);
+        }
+        float4 m = v[4];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            m.x = fmaxf(m.x, v[t].x); m.y = fmaxf(m.y, v[t].y); m.z = fmaxf(m.z, v[t].z); m.w = fmaxf(m.w, v[t].w);
         }
         *reinterpret_cast<float4*>(out + (((size_t)b * Ho + oy) * Wo + ox) * C + c4 * 4) = m;
     }
