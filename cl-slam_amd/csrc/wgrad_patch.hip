@@ -38,8 +38,11 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_patch_kernel(WgPatchK p) {
     constexpr int Z_F4 = BM * COT / 4, P_F4 = PP * CIT / 4;
     constexpr int Z_IT = (Z_F4 + 255) / 256, P_IT = (P_F4 + 255) / 256;
 
-    __shared__ __attribute__((aligned(16))) float Zs[BM * LDZ];
-    __shared__ __attribute__((aligned(16))) float Ps[PP * LDP];
+    // one array: [dZ tile | input patch]; the cross-wave reduction of the epilogue re-uses it from the start
+    constexpr int SMEM = (BM * LDZ + PP * LDP) > (4 * TI * TJ * 256) ? (BM * LDZ + PP * LDP) : (4 * TI * TJ * 256);
+    __shared__ __attribute__((aligned(16))) float smem[SMEM];
+    float* const Zs = smem;
+    float* const Ps = smem + BM * LDZ;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int cot = blockIdx.x % p.co_tiles, cit = blockIdx.x / p.co_tiles;
@@ -51,7 +54,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_patch_kernel(WgPatchK p) {
     const int csrc = fromA ? ci0 : ci0 - p.Ca;
     const int Csrc = fromA ? p.Ca : p.Cb;
 
-    static_assert(4 * TI * TJ * 256 <= BM * LDZ, "cross-wave reduction buffer aliases Zs");
+    static_assert(TW % 4 == 0, "a pixel quad must not straddle two tile rows");
     const float* __restrict__ src = fromA ? p.src_a : p.src_b;   // hoisted: selecting inside the tile loop
                                                                  // re-loads the pointer from the kernarg
     f32x4 acc[9][TI][TJ];
@@ -162,10 +165,10 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_patch_kernel(WgPatchK p) {
     // ---- sum the four waves' accumulators (fixed order) and write this split's partial:
     //      partial[split][co][tap][ci] ---------------------------------------------------------------
     float* out = p.partial + (size_t)split * p.Cout * 9 * Cin;
-    float* red = Zs;   // [wave][TI*TJ][lane][4]
+    float* red = smem;   // [wave][TI*TJ][lane][4]
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
-        __syncthreads();   // Zs free: MFMAs / previous round done
+        __syncthreads();   // tile buffers free: MFMAs / previous round done
 #pragma unroll
         for (int i = 0; i < TI; ++i)
 #pragma unroll
@@ -209,20 +212,47 @@ static void wgp_tile(const clslam_conv_desc* d, int* cot, int* cit) {
     if (*cot == 32 && *cit == 16) *cot = 16;   // instantiated shapes: 16x16, 16x32, 32x32
 }
 
+// Pixel tile: 8x16 on the wide images; the two deep stages of the 192x640 / 384x1280 pyramids get tiles that cover them
+// exactly -- 4x40 on 12x40 (upconv_4_1, upconv_3_0) and 6x20 on 6x20 (upconv_4_0, pose_0 / pose_1) -- instead of the gather
+// kernel (conv_bwd.hip's conv_wgrad_kernel: three shifted copies of the input per 32-pixel chunk, 24 flop per staged byte,
+// MFMA-busy 0.32): one patch serves all nine taps (round 5).  32x32 channel tiles only.
+// OPT-IN (CLSLAM_WGRAD_DEEP_TILES=1).  Measured on MI355X at B = 5 (tools/bench_conv.py): stand-alone upconv_4_1 60 -> 80 TFLOP/s,
+// upconv_3_0 37 -> 43, upconv_4_0 35 -> 41, pose_0/1 37 -> 37, with 4 / 15 / 3 / 5 splits instead of 6 / 19 / 5 / 10 (47 MB fewer
+// split partials per step) -- and inside the step 3.075 vs 3.076 ms, the five-step frame 9.93 vs 9.85 ms: two 252-VGPR / 79 KB
+// workgroups fill a CU's register file, the data-gradient chain they run beside loses what they gain (the same outcome as
+// round 4's weight-tile experiment).
+static void wgp_pixel_tile(const clslam_conv_desc* d, int* th, int* tw) {
+    int cot, cit;
+    wgp_tile(d, &cot, &cit);
+    *th = 8; *tw = 16;
+    const char* env = getenv("CLSLAM_WGRAD_DEEP_TILES");       // (asked when a layer's plan is made, not per launch)
+    const bool deep = env && atoi(env) != 0;
+    if (cot == 32 && cit == 32 && deep) {
+        if (d->out_w == 40 && d->out_h % 4 == 0) { *th = 4; *tw = 40; }
+        else if (d->out_w == 20 && d->out_h == 6) { *th = 6; *tw = 20; }
+    }
+}
+
 }  // namespace clslam
 
 using namespace clslam;
 
 extern "C" int clslam_wgrad_patch_supported(const clslam_conv_desc* d) {
-    return d->ksize == 3 && d->stride == 1 && d->out_h == d->in_h + 2 * d->pad - 2 && d->out_w == d->in_w + 2 * d->pad - 2 &&
-           d->out_w > 40 && d->ch_out % 16 == 0 && (d->ch_a + d->ch_b) % 16 == 0 && d->ch_a % 16 == 0;
+    if (!(d->ksize == 3 && d->stride == 1 && d->out_h == d->in_h + 2 * d->pad - 2 && d->out_w == d->in_w + 2 * d->pad - 2 &&
+          d->ch_out % 16 == 0 && (d->ch_a + d->ch_b) % 16 == 0 && d->ch_a % 16 == 0))
+        return 0;
+    if (d->out_w > 40) return 1;
+    int th, tw;
+    wgp_pixel_tile(d, &th, &tw);
+    return th != 8;          // narrow images: only where an exact tile exists
 }
 
 extern "C" int clslam_wgrad_patch_splits(const clslam_conv_desc* d, int target_blocks) {
-    int cot, cit;
+    int cot, cit, th, tw;
     wgp_tile(d, &cot, &cit);
+    wgp_pixel_tile(d, &th, &tw);
     const int cols = (d->ch_out / cot) * ((d->ch_a + d->ch_b) / cit);
-    const int ntiles = d->batch * cdiv(d->out_h, 8) * cdiv(d->out_w, 16);
+    const int ntiles = d->batch * cdiv(d->out_h, th) * cdiv(d->out_w, tw);
     const int splits = std::max(1, std::min(ntiles, cdiv(target_blocks, cols)));
     const int tps = cdiv(ntiles, splits);
     return cdiv(ntiles, tps);
@@ -231,16 +261,19 @@ extern "C" int clslam_wgrad_patch_splits(const clslam_conv_desc* d, int target_b
 extern "C" int clslam_conv_wgrad_patch(const clslam_conv_desc* d, const float* dz, float* partial, int splits, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     CLSLAM_REQUIRE(d && dz && partial && splits >= 1 && clslam_wgrad_patch_supported(d), "conv_wgrad_patch: unsupported conv");
+    int cot, cit, th, tw;
+    wgp_tile(d, &cot, &cit);
+    wgp_pixel_tile(d, &th, &tw);
     WgPatchK k;
     k.dz = dz; k.src_a = d->src_a; k.src_b = d->src_b; k.partial = partial;
     k.B = d->batch; k.Hi = d->in_h; k.Wi = d->in_w; k.Ca = d->ch_a; k.Cb = d->ch_b; k.Ho = d->out_h; k.Wo = d->out_w;
     k.Cout = d->ch_out; k.pad = d->pad; k.pad_mode = d->pad_mode; k.ups = d->upsample_a;
-    k.tilesX = cdiv(k.Wo, 16); k.tilesY = cdiv(k.Ho, 8);
+    k.tilesX = cdiv(k.Wo, tw); k.tilesY = cdiv(k.Ho, th);
     k.ntiles = k.B * k.tilesX * k.tilesY;
     k.tiles_per_split = cdiv(k.ntiles, splits);
     k.co_tiles = k.ci_tiles = 0;
-    int cot, cit;
-    wgp_tile(d, &cot, &cit);
+    if (th == 4) return launch_wgp<4, 40, 32, 32>(k, splits, stream);
+    if (th == 6) return launch_wgp<6, 20, 32, 32>(k, splits, stream);
     if (cot == 32) return launch_wgp<8, 16, 32, 32>(k, splits, stream);
     if (cit == 32) return launch_wgp<8, 16, 16, 32>(k, splits, stream);
     return launch_wgp<8, 16, 16, 16>(k, splits, stream);

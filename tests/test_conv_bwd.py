@@ -19,6 +19,10 @@ CASES = [
     (1, 16, 32, 32, 0, 16, 3, True, False, 2),    # wgrad_patch 16x32
     (1, 8, 48, 32, 64, 32, 3, True, True, 2),     # wgrad_patch 32x32 with concat
     (2, 9, 40, 64, 0, 64, 3, False, False, 1),    # wgrad_patch 32x32, zero pad
+    (2, 12, 40, 32, 32, 32, 3, True, True, 2),    # wgrad_patch deep-stage tile 4x40 (upconv_4_1-like: upsample + concat, reflect)
+    (1, 12, 40, 64, 0, 32, 3, True, False, 2),    # ... 4x40, one image (upconv_3_0-like)
+    (3, 6, 20, 64, 0, 32, 3, True, False, 2),     # wgrad_patch deep-stage tile 6x20 (upconv_4_0-like)
+    (4, 6, 20, 32, 0, 64, 3, False, False, 1),    # ... 6x20, zero pad (pose_0-like)
 ]
 
 
@@ -36,6 +40,11 @@ def _forward(xa, xb, w_ohwi, bias, k, reflect, ups, act):
     z = F.conv2d(x, w, bias)
     y = F.relu(z) if act == 1 else F.elu(z)
     return z, y
+
+
+@pytest.fixture(autouse=True)
+def _deep_tiles(monkeypatch):
+    monkeypatch.setenv('CLSLAM_WGRAD_DEEP_TILES', '1')      # the opt-in deep-stage tiles of wgrad_patch.hip
 
 
 @pytest.mark.parametrize('backend', BACKENDS)
@@ -74,6 +83,8 @@ def test_conv_backward_matches_autograd(case, backend):
         dw = torch.empty(n, device=dev)
         ops.reduce_partials(partial, dw, n, splits)
         assert rel_err(dw.cpu().view_as(w), w.grad) < 2e-5, (target, splits)
+    if k == 3 and Ca % 32 == 0 and Cb % 32 == 0 and Cout % 32 == 0 and (W, H % 4) == (40, 0) or (H, W) == (6, 20):
+        assert ops.wgrad_patch_supported(desc)          # the deep-stage tiles are on in this file
     if ops.wgrad_patch_supported(desc):
         for target in (1, 16):
             splits = ops.wgrad_patch_splits(desc, target)
