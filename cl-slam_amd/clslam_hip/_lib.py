@@ -87,6 +87,13 @@ _SIGNATURES = {
     'clslam_automask_pyramid': [fptr, fptr, fptr, fptr, fptr, i32, i32, i32, i32, C.c_void_p],
     'clslam_disp_mean_pyramid': [C.POINTER(fptr), fptr, i32, i32, i32, C.c_void_p],
     'clslam_photo_automask_pyramid': [fptr, fptr, fptr, fptr, fptr, fptr, fptr, i32, i32, i32, C.c_void_p],
+    'clslam_warp_fwd_pyramid_range': [C.POINTER(fptr), fptr, fptr, fptr, fptr, fptr, fptr, i32, i32, i32, C.c_float, C.c_float, i32, i32,
+                                      C.c_void_p],
+    'clslam_photo_automask_pyramid_range': [fptr, fptr, fptr, fptr, C.c_uint64, C.c_uint64, fptr, fptr, fptr, i32, i32, i32, i32, i32,
+                                            C.c_void_p],
+    'clslam_loss_bwd2_pyramid_range': [C.POINTER(fptr), fptr, fptr, fptr, fptr, fptr, fptr, fptr, fptr, fptr, fptr, fptr, i32, i32, i32,
+                                       C.c_float, C.c_float, i32, i32, C.c_void_p],
+    'clslam_disp_grad_pyramid_range': [fptr, C.POINTER(fptr), fptr, i32, C.POINTER(fptr), i32, i32, i32, i32, i32, C.c_void_p],
     'clslam_photo_automask_pyramid_rng': [fptr, fptr, fptr, C.c_uint64, C.c_uint64, fptr, fptr, fptr, i32, i32, i32, C.c_void_p],
     'clslam_tie_break_noise': [fptr, C.c_size_t, C.c_uint64, C.c_uint64, C.c_void_p],
     'clslam_smooth_intended_chunks': [],
@@ -140,7 +147,7 @@ _SIGNATURES = {
                                 fptr, C.c_void_p],
 }
 _RESTYPES = {'clslam_last_error': C.c_char_p, 'clslam_last_error_string': C.c_char_p, 'clslam_build_id': C.c_char_p}
-ABI_VERSION = 103          # include/clslam_hip.h CLSLAM_ABI_VERSION: struct layouts / pointer types this binding was written for
+ABI_VERSION = 104          # include/clslam_hip.h CLSLAM_ABI_VERSION: struct layouts / pointer types this binding was written for
 _SIZE_FNS = {'clslam_wino_weight_size': [i32, i32]}      # return size_t
 _PTR_FNS = {'clslam_handoff_event_create': []}             # return void*
 _VOID_FNS = {'clslam_handoff_event_destroy': [C.c_void_p]}

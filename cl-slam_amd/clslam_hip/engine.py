@@ -232,6 +232,15 @@ class Engine:
         # enough to fill it alone) -- hence the band.  CLSLAM_CU_LIMIT=<n> forces a value (0: the whole chip).
         self.cu_limit_env = os.environ.get('CLSLAM_CU_LIMIT')
         self._cu_enc = self._cu_dec = 0     # set per forward(); the stand-alone callables (run_encoder, ...) take the whole chip
+        # OPT-IN experiment (CLSLAM_EARLY_LOSS=1), steps 2..S of adapt(steps=S) (decoders only): the view synthesis, photometric
+        # stage and loss backward of the COARSE scales 3, 2, 1 issued on the leaf stream as soon as their disparity head has run,
+        # beside the decoder levels that follow; only scale 0's remain between the decoder and the data-gradient chain.  The
+        # per-scale launches write bit for bit what the pyramid launch writes (tests/test_loss_stage.py, test_frozen_reuse.py with
+        # the switch on).  Measured on MI355X, 192x640, five-step frame: B = 5 9.85 -> 9.97 ms, B = 3 7.15 -> 7.28, B = 2 5.75 -> 5.86,
+        # B = 1 inside its +-20 % host noise, B = 33 +-0: the decoder's launches already fill every wave slot, the loss kernels only
+        # take turns with them and nine more launches + two more events are paid for nothing.  Off by default.
+        self.early_loss = os.environ.get('CLSLAM_EARLY_LOSS', '0') == '1'
+        self.early_loss_max_pixels = int(os.environ.get('CLSLAM_EARLY_LOSS_MAX_PIXELS', str(1 << 40)))
         self.device_cus = (torch.cuda.get_device_properties(device).multi_processor_count if device.type == 'cuda' else 256)
         # steps 2..S of adapt(steps=S) keep the frozen encoders' features (see forward)
         self.reuse_frozen_features = os.environ.get('CLSLAM_REUSE_FROZEN', '1') != '0'
@@ -588,7 +597,9 @@ class Engine:
             hit = self._wb_cache[prefix] = (w, b)
         return hit
 
-    def _depth_decoder(self, ws, feats: List[torch.Tensor]) -> None:
+    def _depth_decoder(self, ws, feats: List[torch.Tensor], early=None) -> None:
+        """early: callable(scale), run on the leaf stream right behind the disparity head of scales 3, 2, 1 (forward(): the
+        coarse scales' loss stage)"""
         x = feats[4]
         ops.PERSISTENT_CU_LIMIT = self._cu_dec
         # the disparity heads of scales 3..1 are leaves of the chain (only the view synthesis reads them): they go to
@@ -621,6 +632,8 @@ class Engine:
                         leaf.wait_event(ev)
                     with self._on(leaf):
                         ops.dispconv_fwd(x, w.view(9, NUM_CH_DEC[i]), b, ws.disp[i])
+                        if early is not None:
+                            early(i)
                     forked = True
                 else:
                     ops.dispconv_fwd(x, w.view(9, NUM_CH_DEC[i]), b, ws.disp[i])
@@ -744,6 +757,7 @@ class Engine:
             id_ready = torch.cuda.Event()
             id_ready.record(wg)
         have_noise = False
+        early_state = None
         # A host minibatch still crossing PCIe: the identity maps read the un-augmented frames, i.e. they wait for the WHOLE
         # upload -- and so would everything queued behind them on the wgrad stream.  With the downsample convolutions on that
         # stream (single triplets) the first stage entry of the depth encoder must not inherit that wait: the
@@ -777,7 +791,43 @@ class Engine:
                 return self._encoder(self.enc['depth_encoder'], ws.denc, B, [(aug[0], None, 0, B)], stream=main, aux=ds_aux)
             # the host enqueues ~50 launches per branch (~0.7 ms): the depth branch is the longer
             # dependency chain (encoder + decoder), so its kernels go out first
-            if reuse:                   # no encoders to hide the host's launches behind: the long chain goes out first
+            early = (reuse and train and self.early_loss and B * H * W <= self.early_loss_max_pixels and wg is not None
+                     and not self._capturing and ops.PROFILE is None and inputs_ready is None and id_ready is not None)
+            if early:
+                # the pose decoder (short) goes out first, with the projection matrices behind it on its own stream: every scale's
+                # view synthesis waits for them only
+                K = self._mat(inputs['camera_matrix', 0])
+                Kinv = self._mat(inputs['inv_camera_matrix', 0])
+                pf4 = pose_branch()
+                with self._on(side):
+                    ops.pose_to_proj(ws.pose, K, ws.T, ws.P)
+                pose_ready = torch.cuda.Event()
+                pose_ready.record(side)
+                draw = None
+                if not have_noise and draw_noise:
+                    draw = self._next_noise_draw()       # ONE draw per forward: element index = (scale, sample, pixel)
+                waited = [False]
+                t = ws.train
+
+                def early_loss(sc):       # on the leaf (= wgrad) stream, behind dispconv_sc; the identity maps / noise sit on it too
+                    if not waited[0]:
+                        wg.wait_event(pose_ready)
+                        waited[0] = True
+                    ops.warp_fwd_pyramid(ws.disp, rgb[-1], rgb[1], Kinv, ws.P, ws.depth, ws.warped, self.min_depth, self.max_depth,
+                                         scales=(sc, 1))
+                    if draw is None:
+                        ops.photo_automask_pyramid(ws.warped, rgb[0], ws.idmap, ws.noise if have_noise else None, ws.sel, ws.coef,
+                                                   ws.partial, B, H, W, scales=(sc, 1))
+                    else:
+                        ops.photo_automask_pyramid_rng(ws.warped, rgb[0], ws.idmap, draw[0], draw[1], ws.sel, ws.coef, ws.partial,
+                                                       B, H, W, scales=(sc, 1))
+                    ops.loss_bwd2_pyramid(ws.disp, ws.sel, ws.coef, ws.warped, rgb[0], rgb[-1], rgb[1], Kinv, ws.P, sample_w,
+                                          t.ddisp_up, t.dp_partial, self.min_depth, self.max_depth, scales=(sc, 1))
+                dfeats = ws.dfeats
+                self.wait_training(main)
+                self._depth_decoder(ws, dfeats, early=early_loss)
+                early_state = SimpleNamespace(K=K, Kinv=Kinv, draw=draw)
+            elif reuse:                 # no encoders to hide the host's launches behind: the long chain goes out first
                 dfeats = ws.dfeats
                 self.wait_training(main)
                 self._depth_decoder(ws, dfeats)
@@ -808,10 +858,15 @@ class Engine:
         # view synthesis + loss ------------------------------------------------------------------
         if inputs_ready is not None:
             self._main.wait_event(inputs_ready[3])
-        K = self._mat(inputs['camera_matrix', 0])
-        Kinv = self._mat(inputs['inv_camera_matrix', 0])
-        ops.pose_to_proj(ws.pose, K, ws.T, ws.P)
-        ops.warp_fwd_pyramid(ws.disp, rgb[-1], rgb[1], Kinv, ws.P, ws.depth, ws.warped, self.min_depth, self.max_depth)
+        # scales still to do here: all four, or scale 0 only when the coarse ones went out beside the decoder (early_state)
+        rest = (0, 4) if early_state is None else (0, 1)
+        if early_state is None:
+            K = self._mat(inputs['camera_matrix', 0])
+            Kinv = self._mat(inputs['inv_camera_matrix', 0])
+            ops.pose_to_proj(ws.pose, K, ws.T, ws.P)
+        else:
+            K, Kinv = early_state.K, early_state.Kinv
+        ops.warp_fwd_pyramid(ws.disp, rgb[-1], rgb[1], Kinv, ws.P, ws.depth, ws.warped, self.min_depth, self.max_depth, scales=rest)
         if id_ready is not None:
             self._main.wait_event(id_ready)
         else:
@@ -820,13 +875,14 @@ class Engine:
         # SSIM coefficients are kept for the backward
         if have_noise or not draw_noise:
             ops.photo_automask_pyramid(ws.warped, rgb[0], ws.idmap, ws.noise if have_noise else None, ws.sel,
-                                       ws.coef if train else None, ws.partial, B, H, W)
+                                       ws.coef if train else None, ws.partial, B, H, W, scales=rest)
         else:
             # dpp.py:1055-1056 draws randn * 1e-5 on the compute device every scale, every step: here inside the kernel
             # (Philox keyed by torch's seed, one draw offset per forward) -- no noise tensor is written or read
-            seed, offset = self._next_noise_draw()
+            seed, offset = early_state.draw if early_state is not None else self._next_noise_draw()
             ops.photo_automask_pyramid_rng(ws.warped, rgb[0], ws.idmap, seed, offset, ws.sel,
-                                           ws.coef if train else None, ws.partial, B, H, W)
+                                           ws.coef if train else None, ws.partial, B, H, W, scales=rest)
+        ws.loss_bwd_scales = rest       # backward(): the coarse scales' loss backward is already out
         ops.disp_mean_pyramid(ws.disp, ws.means, H, W)
         n_smooth = 0 if (smooth_w is None or self.smooth_intended) else int(smooth_w.numel())
         if n_smooth and not (n_smooth < (W >> 3) - 1):
@@ -1009,7 +1065,9 @@ class Engine:
             t.wt_ready.record(wg)
         # loss -> disparity logits and pose-decoder output ----------------------------------------
         ops.loss_bwd2_pyramid(ws.disp, ws.sel, ws.coef, ws.warped, c.rgb[0], c.rgb[-1], c.rgb[1], c.Kinv, ws.P, c.sample_w,
-                              t.ddisp_up, t.dp_partial, self.min_depth, self.max_depth)
+                              t.ddisp_up, t.dp_partial, self.min_depth, self.max_depth,
+                              scales=getattr(ws, 'loss_bwd_scales', (0, 4)))
+        ws.loss_bwd_scales = (0, 4)
         ops.disp_grad_pyramid(t.ddisp_up, ws.disp, c.aux if c.n_smooth else None, c.n_smooth, t.dz_disp, H, W)
         if self.smooth_intended:
             ops.smooth_intended_bwd(ws.disp, c.rgb0, ws.si_aux, c.sample_w, t.dz_disp, H, W, self.smooth_scale)

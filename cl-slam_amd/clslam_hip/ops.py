@@ -527,10 +527,11 @@ def _ptr4(tensors):
     return (C.c_void_p * 4)(*[_p(t) for t in tensors])
 
 
-def warp_fwd_pyramid(disps, src_m1, src_p1, inv_k, proj, depth, warped, min_depth, max_depth):
+def warp_fwd_pyramid(disps, src_m1, src_p1, inv_k, proj, depth, warped, min_depth, max_depth, scales=(0, 4)):
+    """scales = (first, count): that part of the pyramid only (same buffers)"""
     B, H, W = depth.shape[1], depth.shape[-2], depth.shape[-1]
-    _lib.get_lib().call('clslam_warp_fwd_pyramid', _ptr4(disps), _p(src_m1), _p(src_p1), _p(inv_k), _p(proj), _p(depth),
-                        _p(warped), B, H, W, _nd(min_depth), _nd(max_depth), _stream(depth))
+    _lib.get_lib().call('clslam_warp_fwd_pyramid_range', _ptr4(disps), _p(src_m1), _p(src_p1), _p(inv_k), _p(proj), _p(depth),
+                        _p(warped), B, H, W, _nd(min_depth), _nd(max_depth), scales[0], scales[1], _stream(depth))
 
 
 def warp_cells_pyramid(disps, inv_k, proj, cells, min_depth, max_depth):
@@ -570,20 +571,22 @@ def loss_bwd_pyramid(disps, sel, coef, warped, target, src_m1, src_p1, inv_k, pr
                         _nd(min_depth), _nd(max_depth), _stream(ddisp_up))
 
 
-def disp_grad_pyramid(ddisp_up, disps, smooth_aux, n_smooth, dzs, H, W):
-    _lib.get_lib().call('clslam_disp_grad_pyramid', _p(ddisp_up), _ptr4(disps), _p(smooth_aux), n_smooth, _ptr4(dzs),
-                        disps[0].shape[0], H, W, _stream(ddisp_up))
+def disp_grad_pyramid(ddisp_up, disps, smooth_aux, n_smooth, dzs, H, W, scales=(0, 4)):
+    _lib.get_lib().call('clslam_disp_grad_pyramid_range', _p(ddisp_up), _ptr4(disps), _p(smooth_aux), n_smooth, _ptr4(dzs),
+                        disps[0].shape[0], H, W, scales[0], scales[1], _stream(ddisp_up))
 
 
-def photo_automask_pyramid(warped, target, idmap, noise, sel, coef_sel, partial, batch, H, W):
-    _lib.get_lib().call('clslam_photo_automask_pyramid', _p(warped), _p(target), _p(idmap), _p(noise), _pa(sel, torch.uint8),
-                        _p(coef_sel), _p(partial), batch, H, W, _stream(warped))
+def photo_automask_pyramid(warped, target, idmap, noise, sel, coef_sel, partial, batch, H, W, scales=(0, 4)):
+    _lib.get_lib().call('clslam_photo_automask_pyramid_range', _p(warped), _p(target), _p(idmap), _p(noise), 0, 0, _pa(sel, torch.uint8),
+                        _p(coef_sel), _p(partial), batch, H, W, scales[0], scales[1], _stream(warped))
 
 
-def photo_automask_pyramid_rng(warped, target, idmap, seed, offset, sel, coef_sel, partial, batch, H, W):
+def photo_automask_pyramid_rng(warped, target, idmap, seed, offset, sel, coef_sel, partial, batch, H, W, scales=(0, 4)):
     """tie-break noise drawn in the kernel (Philox): seed != 0, offset = draw counter of the step"""
-    _lib.get_lib().call('clslam_photo_automask_pyramid_rng', _p(warped), _p(target), _p(idmap), int(seed), int(offset),
-                        _pa(sel, torch.uint8), _p(coef_sel), _p(partial), batch, H, W, _stream(warped))
+    if not seed:
+        raise _lib.ClslamError('photo_automask_pyramid_rng: seed must be non-zero')
+    _lib.get_lib().call('clslam_photo_automask_pyramid_range', _p(warped), _p(target), _p(idmap), None, int(seed), int(offset),
+                        _pa(sel, torch.uint8), _p(coef_sel), _p(partial), batch, H, W, scales[0], scales[1], _stream(warped))
 
 
 def tie_break_noise(out, seed, offset):
@@ -616,8 +619,8 @@ def loss_bwd2_blocks(H, W) -> int:
 
 
 def loss_bwd2_pyramid(disps, sel, coef_sel, warped, target, src_m1, src_p1, inv_k, proj, sample_w, ddisp_up, dp_partial,
-                      min_depth, max_depth):
+                      min_depth, max_depth, scales=(0, 4)):
     B, H, W = ddisp_up.shape[1], ddisp_up.shape[-2], ddisp_up.shape[-1]
-    _lib.get_lib().call('clslam_loss_bwd2_pyramid', _ptr4(disps), _pa(sel, torch.uint8), _p(coef_sel), _p(warped), _p(target),
+    _lib.get_lib().call('clslam_loss_bwd2_pyramid_range', _ptr4(disps), _pa(sel, torch.uint8), _p(coef_sel), _p(warped), _p(target),
                         _p(src_m1), _p(src_p1), _p(inv_k), _p(proj), _p(sample_w), _p(ddisp_up), _pa(dp_partial, torch.float64), B, H, W,
-                        _nd(min_depth), _nd(max_depth), _stream(ddisp_up))
+                        _nd(min_depth), _nd(max_depth), scales[0], scales[1], _stream(ddisp_up))

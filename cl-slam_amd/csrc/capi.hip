@@ -143,7 +143,8 @@ extern "C" int clslam_handoff_wait(void* event, void* producer_stream, void* con
 // 101: clslam_conv_desc grew `weight_wino` (appended), double dp_partial in the loss backward entry points
 // 102: clslam_conv_desc grew `cu_limit` (appended)
 // 103: clslam_handoff_* (additive)
-extern "C" int clslam_version(void) { return 103; }
+// 104: clslam_*_pyramid_range (additive)
+extern "C" int clslam_version(void) { return 104; }
 // identity of the kernel sources this library was LINKED from (csrc/build.py passes it when it compiles this file, which it
 // does whenever any object is rebuilt): read from the loaded library, not from a file beside it
 #ifndef CLSLAM_BUILD_ID

@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void warp_fwd_kernel(Pyramid pyr, const float*
                                                        const float* __restrict__ P, float* __restrict__ depth_all,
                                                        float* __restrict__ warped_all, int B, int H, int W, float da, float db,
                                                        int dmode, int tilesX) {
-    const int b = blockIdx.y, sc = blockIdx.z;
+    const int b = blockIdx.y, sc = blockIdx.z + pyr.base;
     const int ty = blockIdx.x / tilesX, tx = blockIdx.x - ty * tilesX;
     const int x = tx * WF_TW + (int)(threadIdx.x & 63), y = ty * WF_TH + (int)(threadIdx.x >> 6);
     if (x >= W || y >= H) return;
@@ -327,7 +327,7 @@ extern "C" int clslam_warp_fwd(const float* disp_s, int h, int w, const float* s
     const size_t total = (size_t)batch * H * W;
     if (!total) return CLSLAM_OK;
     Pyramid pyr;
-    pyr.n = 1; pyr.disp[0] = disp_s; pyr.h[0] = h; pyr.w[0] = w;
+    pyr.n = 1; pyr.base = 0; pyr.disp[0] = disp_s; pyr.h[0] = h; pyr.w[0] = w;
     for (int k = 1; k < 4; ++k) { pyr.disp[k] = nullptr; pyr.h[k] = pyr.w[k] = 0; }
     const int tilesX = cdiv(W, WF_TW);
     hipLaunchKernelGGL(warp_fwd_kernel, dim3(tilesX * cdiv(H, WF_TH), batch, 1), dim3(256), 0,
@@ -336,23 +336,31 @@ extern "C" int clslam_warp_fwd(const float* disp_s, int h, int w, const float* s
 }
 
 // All four scales in one launch: disp[s] (B,H>>s,W>>s); depth (4,B,H,W); warped (4,2,B,3,H,W).
-extern "C" int clslam_warp_fwd_pyramid(const float* const* disp, const float* src_m1, const float* src_p1, const float* inv_k,
-                                       const float* proj, float* depth, float* warped, int batch, int H, int W,
-                                       float min_depth, float max_depth, void* stream) {
+extern "C" int clslam_warp_fwd_pyramid_range(const float* const* disp, const float* src_m1, const float* src_p1, const float* inv_k,
+                                             const float* proj, float* depth, float* warped, int batch, int H, int W,
+                                             float min_depth, float max_depth, int scale_lo, int scale_count, void* stream) {
     CLSLAM_REQUIRE(disp && src_m1 && src_p1 && inv_k && proj && depth && warped, "warp_fwd_pyramid: null");
     CLSLAM_REQUIRE(!(min_depth <= 0.f && max_depth > 0.f), "warp_fwd_pyramid: min_depth is None");
+    CLSLAM_REQUIRE(scale_lo >= 0 && scale_count >= 0 && scale_lo + scale_count <= 4, "warp_fwd_pyramid: scales [%d, %d) outside the pyramid",
+                   scale_lo, scale_lo + scale_count);
     float a, b; int mode;
     depth_mode(min_depth, max_depth, &a, &b, &mode);
     Pyramid pyr;
-    pyr.n = 4;
+    pyr.n = 4; pyr.base = scale_lo;
     for (int k = 0; k < 4; ++k) { pyr.disp[k] = disp[k]; pyr.h[k] = H >> k; pyr.w[k] = W >> k; }
     const size_t total = (size_t)4 * batch * H * W;
-    if (!total) return CLSLAM_OK;
+    if (!total || !scale_count) return CLSLAM_OK;
     CLSLAM_REQUIRE(total < ((size_t)1 << 31), "warp_fwd_pyramid: batch too large for 32-bit indexing");
     const int tilesX = cdiv(W, WF_TW);
-    hipLaunchKernelGGL(warp_fwd_kernel, dim3(tilesX * cdiv(H, WF_TH), batch, 4), dim3(256), 0,
+    hipLaunchKernelGGL(warp_fwd_kernel, dim3(tilesX * cdiv(H, WF_TH), batch, scale_count), dim3(256), 0,
                        (hipStream_t)stream, pyr, src_m1, src_p1, inv_k, proj, depth, warped, batch, H, W, a, b, mode, tilesX);
     return check_launch("warp_fwd_pyramid");
+}
+
+extern "C" int clslam_warp_fwd_pyramid(const float* const* disp, const float* src_m1, const float* src_p1, const float* inv_k,
+                                       const float* proj, float* depth, float* warped, int batch, int H, int W,
+                                       float min_depth, float max_depth, void* stream) {
+    return clslam_warp_fwd_pyramid_range(disp, src_m1, src_p1, inv_k, proj, depth, warped, batch, H, W, min_depth, max_depth, 0, 4, stream);
 }
 
 // Diagnostic twin of warp_fwd_kernel (tests/test_backward_parity.py): the bilinear CELL and the border-clip flags the
@@ -394,7 +402,7 @@ extern "C" int clslam_warp_cells_pyramid(const float* const* disp, const float* 
     float a, b; int mode;
     depth_mode(min_depth, max_depth, &a, &b, &mode);
     Pyramid pyr;
-    pyr.n = 4;
+    pyr.n = 4; pyr.base = 0;
     for (int k = 0; k < 4; ++k) { pyr.disp[k] = disp[k]; pyr.h[k] = H >> k; pyr.w[k] = W >> k; }
     if (!batch) return CLSLAM_OK;
     const int tilesX = cdiv(W, WF_TW);
@@ -436,7 +444,7 @@ extern "C" int clslam_warp_coords_pyramid(const float* const* disp, const float*
     float a, b; int mode;
     depth_mode(min_depth, max_depth, &a, &b, &mode);
     Pyramid pyr;
-    pyr.n = 4;
+    pyr.n = 4; pyr.base = 0;
     for (int k = 0; k < 4; ++k) { pyr.disp[k] = disp[k]; pyr.h[k] = H >> k; pyr.w[k] = W >> k; }
     if (!batch) return CLSLAM_OK;
     const int tilesX = cdiv(W, WF_TW);

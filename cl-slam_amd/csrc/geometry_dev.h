@@ -11,6 +11,7 @@ struct Pyramid {
     const float* disp[4];
     int h[4], w[4];
     int n;
+    int base;      // first scale of THIS launch (warp_fwd / loss_bwd2 / disp_grad take a sub-range of the pyramid: grid index + base)
 };
 
 // EVERY function between a disparity and a bilinear cell below has floating-point contraction switched off.  The forward

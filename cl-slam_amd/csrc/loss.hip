@@ -86,14 +86,14 @@ __global__ __launch_bounds__(256) void photo_automask_kernel(const float* __rest
                                                              const float* __restrict__ idmap, const float* __restrict__ noise_all,
                                                              unsigned char* __restrict__ sel_all, float* __restrict__ coef_sel_all,
                                                              float* __restrict__ partial_all, int B, int H, int W, int tilesX,
-                                                             unsigned long long seed, unsigned long long rng_offset) {
+                                                             unsigned long long seed, unsigned long long rng_offset, int sc0) {
     // The two source frames of a pixel travel as ONE packed pair (f32x2 = v_pk_* arithmetic, ds_read_b64): the kernel is
     // VALU-bound (~900 issue slots per pixel before, two thirds of them per frame), not LDS- or HBM-bound.
     __shared__ float tl[3][PA_PH * PA_PW];   // target
     __shared__ f32x2 tw[3][PA_PH * PA_PW];   // warped (frame 0, frame 1)
     __shared__ float red[4];
     const float C1 = 0.0001f, C2 = 0.0009f;
-    const int b = blockIdx.y, sc = blockIdx.z;
+    const int b = blockIdx.y, sc = blockIdx.z + sc0;      // sc0: first scale of this launch
     const int HW = H * W;
     const int ty = blockIdx.x / tilesX, tx = blockIdx.x - ty * tilesX;
     const int y0 = ty * PA_TH, x0 = tx * PA_TW;
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256) void loss_bwd2_kernel(Pyramid pyr, const unsig
     __shared__ f32x2 cs[LB_PH * LB_PW][5];
     __shared__ unsigned char ss[LB_PH * LB_PW];
     __shared__ double red[4][24];     // the pose-gradient sums leave the thread in double (wave_sum_f64)
-    const int b = blockIdx.y, sc = blockIdx.z;
+    const int b = blockIdx.y, sc = blockIdx.z + pyr.base;
     const int HW = H * W;
     const int ty = blockIdx.x / tilesX, tx = blockIdx.x - ty * tilesX;
     const int y0 = ty * LB_TH, x0 = tx * LB_TW;
@@ -793,7 +793,7 @@ __global__ __launch_bounds__(256) void disp_grad_kernel(const float* ddisp_up, c
 // read consecutive X), then xor-shuffle reduce: every scale exposes B*H*W threads of equal work.
 __global__ __launch_bounds__(256) void disp_grad_coop_kernel(const float* __restrict__ ddisp_up_all, const float* __restrict__ smooth_all,
                                                              int n_smooth, int B, int H, int W, Pyramid pyr, DzPtrs dzp) {
-    const int sc = blockIdx.y;
+    const int sc = blockIdx.y + pyr.base;
     const int h = pyr.h[sc], w = pyr.w[sc];
     const int f = H / h, G = f * f;
     const float* __restrict__ disp = pyr.disp[sc];
@@ -899,7 +899,7 @@ extern "C" int clslam_disp_mean(const float* disp, float* means, int batch, int 
     CLSLAM_REQUIRE(disp && means, "disp_mean: null");
     if (!batch) return CLSLAM_OK;
     Pyramid pyr;
-    pyr.n = 1; pyr.disp[0] = disp; pyr.h[0] = 1; pyr.w[0] = hw;
+    pyr.n = 1; pyr.base = 0; pyr.disp[0] = disp; pyr.h[0] = 1; pyr.w[0] = hw;
     for (int k = 1; k < 4; ++k) { pyr.disp[k] = nullptr; pyr.h[k] = pyr.w[k] = 0; }
     hipLaunchKernelGGL(disp_mean_kernel, dim3(DM_CHUNKS, batch, 1), dim3(256), 0, (hipStream_t)stream, pyr, means, batch);
     return check_launch("disp_mean");
@@ -907,7 +907,7 @@ extern "C" int clslam_disp_mean(const float* disp, float* means, int batch, int 
 
 static Pyramid make_pyramid(const float* const* disp, int H, int W) {
     Pyramid pyr;
-    pyr.n = 4;
+    pyr.n = 4; pyr.base = 0;
     for (int k = 0; k < 4; ++k) { pyr.disp[k] = disp[k]; pyr.h[k] = H >> k; pyr.w[k] = W >> k; }
     return pyr;
 }
@@ -925,31 +925,43 @@ extern "C" int clslam_disp_mean_pyramid(const float* const* disp, float* psum, i
 // sel (4,B,H,W), coef_sel (4,B,9,H,W)|NULL (training only), partial (4,B,clslam_automask_blocks).
 static int photo_automask_launch(const float* warped, const float* target, const float* idmap, const float* noise,
                                  unsigned char* sel, float* coef_sel, float* partial, int batch, int H, int W,
-                                 unsigned long long seed, unsigned long long offset, void* stream) {
+                                 unsigned long long seed, unsigned long long offset, int scale_lo, int scale_count, void* stream) {
     CLSLAM_REQUIRE(warped && target && idmap && sel && partial && H >= 2 && W >= 2, "photo_automask_pyramid: bad args");
-    if (!batch) return CLSLAM_OK;
+    CLSLAM_REQUIRE(scale_lo >= 0 && scale_count >= 0 && scale_lo + scale_count <= 4, "photo_automask_pyramid: scales [%d, %d) outside the pyramid",
+                   scale_lo, scale_lo + scale_count);
+    if (!batch || !scale_count) return CLSLAM_OK;
     const int nblk = clslam_automask_blocks(H, W);   // = number of 8 x 64 tiles
     const int tilesX = cdiv(W, PA_TW);
     if (coef_sel)
-        hipLaunchKernelGGL(photo_automask_kernel<true>, dim3(nblk, batch, 4), dim3(256), 0, (hipStream_t)stream, warped, target,
-                           idmap, noise, sel, coef_sel, partial, batch, H, W, tilesX, seed, offset);
+        hipLaunchKernelGGL(photo_automask_kernel<true>, dim3(nblk, batch, scale_count), dim3(256), 0, (hipStream_t)stream, warped, target,
+                           idmap, noise, sel, coef_sel, partial, batch, H, W, tilesX, seed, offset, scale_lo);
     else
-        hipLaunchKernelGGL(photo_automask_kernel<false>, dim3(nblk, batch, 4), dim3(256), 0, (hipStream_t)stream, warped, target,
-                           idmap, noise, sel, coef_sel, partial, batch, H, W, tilesX, seed, offset);
+        hipLaunchKernelGGL(photo_automask_kernel<false>, dim3(nblk, batch, scale_count), dim3(256), 0, (hipStream_t)stream, warped, target,
+                           idmap, noise, sel, coef_sel, partial, batch, H, W, tilesX, seed, offset, scale_lo);
     return check_launch("photo_automask_pyramid");
 }
 
 extern "C" int clslam_photo_automask_pyramid(const float* warped, const float* target, const float* idmap, const float* noise,
                                              unsigned char* sel, float* coef_sel, float* partial, int batch, int H, int W,
                                              void* stream) {
-    return photo_automask_launch(warped, target, idmap, noise, sel, coef_sel, partial, batch, H, W, 0ull, 0ull, stream);
+    return photo_automask_launch(warped, target, idmap, noise, sel, coef_sel, partial, batch, H, W, 0ull, 0ull, 0, 4, stream);
 }
 
 extern "C" int clslam_photo_automask_pyramid_rng(const float* warped, const float* target, const float* idmap,
                                                  unsigned long long seed, unsigned long long offset, unsigned char* sel,
                                                  float* coef_sel, float* partial, int batch, int H, int W, void* stream) {
     CLSLAM_REQUIRE(seed != 0, "photo_automask_pyramid_rng: seed must be non-zero");
-    return photo_automask_launch(warped, target, idmap, nullptr, sel, coef_sel, partial, batch, H, W, seed, offset, stream);
+    return photo_automask_launch(warped, target, idmap, nullptr, sel, coef_sel, partial, batch, H, W, seed, offset, 0, 4, stream);
+}
+
+// scales [scale_lo, scale_lo + scale_count) only: noise injected (noise != NULL), drawn in the kernel (seed != 0) or absent
+extern "C" int clslam_photo_automask_pyramid_range(const float* warped, const float* target, const float* idmap, const float* noise,
+                                                   unsigned long long seed, unsigned long long offset, unsigned char* sel,
+                                                   float* coef_sel, float* partial, int batch, int H, int W, int scale_lo,
+                                                   int scale_count, void* stream) {
+    CLSLAM_REQUIRE(!(noise && seed), "photo_automask_pyramid_range: injected noise and an in-kernel draw exclude each other");
+    return photo_automask_launch(warped, target, idmap, noise, sel, coef_sel, partial, batch, H, W, seed, offset, scale_lo, scale_count,
+                                 stream);
 }
 
 extern "C" int clslam_tie_break_noise(float* out, size_t npix, unsigned long long seed, unsigned long long offset, void* stream) {
@@ -964,20 +976,33 @@ extern "C" int clslam_loss_bwd2_blocks(int H, int W) { return cdiv(H, LB_TH) * c
 
 // LDS-tiled fused loss backward on the selected-frame coefficients (clslam_photo_automask_pyramid);
 // dp_partial [4][B][clslam_loss_bwd2_blocks][24].
+extern "C" int clslam_loss_bwd2_pyramid_range(const float* const* disp, const unsigned char* sel, const float* coef_sel,
+                                              const float* warped, const float* target, const float* src_m1, const float* src_p1,
+                                              const float* inv_k, const float* proj, const float* sample_w, float* ddisp_up,
+                                              double* dp_partial, int batch, int H, int W, float min_depth, float max_depth,
+                                              int scale_lo, int scale_count, void* stream) {
+    CLSLAM_REQUIRE(disp && sel && coef_sel && warped && target && src_m1 && src_p1 && inv_k && proj && sample_w && ddisp_up &&
+                   dp_partial, "loss_bwd2_pyramid: null");
+    CLSLAM_REQUIRE(scale_lo >= 0 && scale_count >= 0 && scale_lo + scale_count <= 4, "loss_bwd2_pyramid: scales [%d, %d) outside the pyramid",
+                   scale_lo, scale_lo + scale_count);
+    float a, b; int mode;
+    depth_mode(min_depth, max_depth, &a, &b, &mode);
+    if (!batch || !scale_count) return CLSLAM_OK;
+    const int tilesX = cdiv(W, LB_TW);
+    Pyramid pyr = make_pyramid(disp, H, W);
+    pyr.base = scale_lo;
+    hipLaunchKernelGGL(loss_bwd2_kernel, dim3(clslam_loss_bwd2_blocks(H, W), batch, scale_count), dim3(256), 0, (hipStream_t)stream,
+                       pyr, sel, coef_sel, warped, target, src_m1, src_p1, inv_k, proj, sample_w, ddisp_up,
+                       dp_partial, batch, H, W, a, b, mode, tilesX);
+    return check_launch("loss_bwd2_pyramid");
+}
+
 extern "C" int clslam_loss_bwd2_pyramid(const float* const* disp, const unsigned char* sel, const float* coef_sel,
                                         const float* warped, const float* target, const float* src_m1, const float* src_p1,
                                         const float* inv_k, const float* proj, const float* sample_w, float* ddisp_up,
                                         double* dp_partial, int batch, int H, int W, float min_depth, float max_depth, void* stream) {
-    CLSLAM_REQUIRE(disp && sel && coef_sel && warped && target && src_m1 && src_p1 && inv_k && proj && sample_w && ddisp_up &&
-                   dp_partial, "loss_bwd2_pyramid: null");
-    float a, b; int mode;
-    depth_mode(min_depth, max_depth, &a, &b, &mode);
-    if (!batch) return CLSLAM_OK;
-    const int tilesX = cdiv(W, LB_TW);
-    hipLaunchKernelGGL(loss_bwd2_kernel, dim3(clslam_loss_bwd2_blocks(H, W), batch, 4), dim3(256), 0, (hipStream_t)stream,
-                       make_pyramid(disp, H, W), sel, coef_sel, warped, target, src_m1, src_p1, inv_k, proj, sample_w, ddisp_up,
-                       dp_partial, batch, H, W, a, b, mode, tilesX);
-    return check_launch("loss_bwd2_pyramid");
+    return clslam_loss_bwd2_pyramid_range(disp, sel, coef_sel, warped, target, src_m1, src_p1, inv_k, proj, sample_w, ddisp_up, dp_partial,
+                                          batch, H, W, min_depth, max_depth, 0, 4, stream);
 }
 
 extern "C" int clslam_loss_bwd_blocks(int H, int W) { return std::max(1, std::min(256, cdiv(H * W, 1024))); }
@@ -1038,16 +1063,25 @@ extern "C" int clslam_disp_grad(const float* ddisp_up, const float* disp, const 
 }
 
 // all four scales in one launch: ddisp_up (4,B,H,W), smooth_aux [4][2+2*n_smooth], dz[s] (B,H>>s,W>>s)
-extern "C" int clslam_disp_grad_pyramid(const float* ddisp_up, const float* const* disp, const float* smooth_aux, int n_smooth,
-                                        float* const* dz, int batch, int H, int W, void* stream) {
+extern "C" int clslam_disp_grad_pyramid_range(const float* ddisp_up, const float* const* disp, const float* smooth_aux, int n_smooth,
+                                              float* const* dz, int batch, int H, int W, int scale_lo, int scale_count, void* stream) {
     CLSLAM_REQUIRE(ddisp_up && disp && dz, "disp_grad_pyramid: null");
     CLSLAM_REQUIRE(n_smooth == 0 || (smooth_aux && n_smooth < (W >> 3) - 1 && (H >> 3) >= 2), "disp_grad_pyramid: smoothness layout unsupported");
-    if (!batch) return CLSLAM_OK;
+    CLSLAM_REQUIRE(scale_lo >= 0 && scale_count >= 0 && scale_lo + scale_count <= 4, "disp_grad_pyramid: scales [%d, %d) outside the pyramid",
+                   scale_lo, scale_lo + scale_count);
+    if (!batch || !scale_count) return CLSLAM_OK;
     DzPtrs dzp; for (int k = 0; k < 4; ++k) dzp.dz[k] = dz[k];
     CLSLAM_REQUIRE(H % 8 == 0 && W % 8 == 0 && (size_t)batch * H * W < ((size_t)1 << 31), "disp_grad_pyramid: H, W must be multiples of 8");
-    hipLaunchKernelGGL(disp_grad_coop_kernel, dim3(cdiv(batch * H * W, 256), 4), dim3(256), 0, (hipStream_t)stream, ddisp_up,
-                       smooth_aux, n_smooth, batch, H, W, make_pyramid(disp, H, W), dzp);
+    Pyramid pyr = make_pyramid(disp, H, W);
+    pyr.base = scale_lo;
+    hipLaunchKernelGGL(disp_grad_coop_kernel, dim3(cdiv(batch * H * W, 256), scale_count), dim3(256), 0, (hipStream_t)stream, ddisp_up,
+                       smooth_aux, n_smooth, batch, H, W, pyr, dzp);
     return check_launch("disp_grad_pyramid");
+}
+
+extern "C" int clslam_disp_grad_pyramid(const float* ddisp_up, const float* const* disp, const float* smooth_aux, int n_smooth,
+                                        float* const* dz, int batch, int H, int W, void* stream) {
+    return clslam_disp_grad_pyramid_range(ddisp_up, disp, smooth_aux, n_smooth, dz, batch, H, W, 0, 4, stream);
 }
 
 

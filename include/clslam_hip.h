@@ -39,9 +39,9 @@ extern "C" {
 
 /* Library identification / error text (thread-local). */
 /* ABI version: 101 = clslam_conv_desc.weight_wino appended, clslam_wino_weight_*; 100 -> 101 also covers the double* dp_partial of
- * clslam_warp_bwd / clslam_pose_bwd / clslam_loss_bwd*_pyramid (round 4); 102 = clslam_conv_desc.cu_limit appended; 103 = clslam_handoff_* added.
+ * clslam_warp_bwd / clslam_pose_bwd / clslam_loss_bwd*_pyramid (round 4); 102 = clslam_conv_desc.cu_limit appended; 103 = clslam_handoff_* added; 104 = ..._pyramid_range entry points added.
  * Bindings check it before the first call.                                                                                    */
-#define CLSLAM_ABI_VERSION 103
+#define CLSLAM_ABI_VERSION 104
 int clslam_version(void);
 const char* clslam_last_error(void);
 const char* clslam_last_error_string(void); /* = clslam_last_error (the name SURVEY.md 8b lists) */
@@ -214,6 +214,13 @@ int clslam_warp_fwd(const float* disp_s, int h, int w, const float* src_m1, cons
 int clslam_warp_fwd_pyramid(const float* const* disp, const float* src_m1, const float* src_p1, const float* inv_k,
                             const float* proj, float* depth, float* warped, int batch, int H, int W, float min_depth,
                             float max_depth, void* stream);
+/* ..._range: scales [scale_lo, scale_lo + scale_count) of the same pyramid only (the same buffers, the same per-scale
+ * arithmetic: four single-scale launches write bit for bit what the one launch writes).  The engine issues the coarse
+ * scales' view synthesis + photometric stage + loss backward as soon as their disparity exists, beside the depth decoder's
+ * remaining levels (round 5; no reference counterpart: dpp.py:981-1076 loops over the scales after the decoder).      */
+int clslam_warp_fwd_pyramid_range(const float* const* disp, const float* src_m1, const float* src_p1, const float* inv_k,
+                                  const float* proj, float* depth, float* warped, int batch, int H, int W, float min_depth,
+                                  float max_depth, int scale_lo, int scale_count, void* stream);
 /* Diagnostic (parity tests): the bilinear cell and border-clip flags the path uses per (scale, source frame, sample,
  * pixel) -- what F.grid_sample decides internally at dpp.py:1013-1017.  cells (4,2,B,H,W) int32 =
  * x0 | y0 << 12 | (x not clipped) << 24 | (y not clipped) << 25; same arguments as clslam_warp_fwd_pyramid.          */
@@ -265,6 +272,10 @@ int clslam_photo_automask_pyramid(const float* warped, const float* target, cons
 int clslam_photo_automask_pyramid_rng(const float* warped, const float* target, const float* idmap, unsigned long long seed,
                                       unsigned long long offset, unsigned char* sel, float* coef_sel, float* partial, int batch,
                                       int H, int W, void* stream);
+/* scales [scale_lo, scale_lo + scale_count): noise injected (noise != NULL), drawn in the kernel (seed != 0) or absent (both 0) */
+int clslam_photo_automask_pyramid_range(const float* warped, const float* target, const float* idmap, const float* noise,
+                                        unsigned long long seed, unsigned long long offset, unsigned char* sel, float* coef_sel,
+                                        float* partial, int batch, int H, int W, int scale_lo, int scale_count, void* stream);
 int clslam_tie_break_noise(float* out, size_t npix, unsigned long long seed, unsigned long long offset, void* stream);
 /* Opt-in "intended" smoothness (the per-sample edge-aware term of monodepth2 instead of the flattened-batch
  * behaviour of dpp.py:1148-1176 that the default mode reproduces).  fwd: partial[4][B][clslam_smooth_intended_chunks()]
@@ -285,6 +296,10 @@ int clslam_loss_bwd2_pyramid(const float* const* disp, const unsigned char* sel,
                              const float* target, const float* src_m1, const float* src_p1, const float* inv_k,
                              const float* proj, const float* sample_w, float* ddisp_up, double* dp_partial, int batch,
                              int H, int W, float min_depth, float max_depth, void* stream);
+int clslam_loss_bwd2_pyramid_range(const float* const* disp, const unsigned char* sel, const float* coef_sel, const float* warped,
+                                   const float* target, const float* src_m1, const float* src_p1, const float* inv_k,
+                                   const float* proj, const float* sample_w, float* ddisp_up, double* dp_partial, int batch,
+                                   int H, int W, float min_depth, float max_depth, int scale_lo, int scale_count, void* stream);
 /* Fused clslam_photo_grad + clslam_warp_bwd for all four scales: sel (4,B,H,W), coef (4,2,B,9,H,W),
  * warped (4,2,B,3,H,W) -> ddisp_up (4,B,H,W), dp_partial [4][B][clslam_loss_bwd_blocks][24].          */
 int clslam_loss_bwd_blocks(int H, int W);
@@ -294,6 +309,8 @@ int clslam_loss_bwd_pyramid(const float* const* disp, const unsigned char* sel, 
                             int W, float min_depth, float max_depth, void* stream);
 int clslam_disp_grad_pyramid(const float* ddisp_up, const float* const* disp, const float* smooth_aux, int n_smooth,
                              float* const* dz, int batch, int H, int W, void* stream);
+int clslam_disp_grad_pyramid_range(const float* ddisp_up, const float* const* disp, const float* smooth_aux, int n_smooth,
+                                   float* const* dz, int batch, int H, int W, int scale_lo, int scale_count, void* stream);
 int clslam_disp_mean_chunks(void);
 int clslam_disp_mean(const float* disp, float* psum, int batch, int hw, void* stream);
 typedef struct clslam_loss_desc {

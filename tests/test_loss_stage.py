@@ -23,8 +23,11 @@ def _run_loss_stage(dev, inputs, disp, pose, noise, sample_w, smooth_w, H, W, mi
     depth = torch.empty(4, B, H, W, device=dev)
     warped = torch.empty(4, 2, B, 3, H, W, device=dev)
     disp_d = [t(d) for d in disp]
+    # pyramid == 'split': the engine's early schedule -- scales 3, 2, 1, 0 as four launches of every pyramid kernel
+    ranges = [(3, 1), (2, 1), (1, 1), (0, 1)] if pyramid == 'split' else [(0, 4)]
     if pyramid:
-        ops.warp_fwd_pyramid(disp_d, src[-1], src[1], Kinv, P, depth, warped, min_depth, max_depth)
+        for r in ranges:
+            ops.warp_fwd_pyramid(disp_d, src[-1], src[1], Kinv, P, depth, warped, min_depth, max_depth, scales=r)
     else:
         for s in range(4):
             ops.warp_fwd(disp_d[s], src[-1], src[1], Kinv, P, depth[s], warped[s], min_depth, max_depth)
@@ -40,7 +43,8 @@ def _run_loss_stage(dev, inputs, disp, pose, noise, sample_w, smooth_w, H, W, mi
     if pyramid:   # the engine's path: fused map+automask (selected-frame coefficients), LDS-tiled backward
         noise_all = torch.stack([t(noise[s]) for s in range(4)]).contiguous() if noise is not None else None
         coef_sel = torch.empty(4, B, 9, H, W, device=dev) if train else None
-        ops.photo_automask_pyramid(warped, src[0], idmap, noise_all, sel, coef_sel, partial, B, H, W)
+        for r in ranges:
+            ops.photo_automask_pyramid(warped, src[0], idmap, noise_all, sel, coef_sel, partial, B, H, W, scales=r)
         ops.disp_mean_pyramid(disp_d, means, H, W)
     else:
         for s in range(4):
@@ -55,7 +59,7 @@ def _run_loss_stage(dev, inputs, disp, pose, noise, sample_w, smooth_w, H, W, mi
     ops.loss_finalize([partial[s] for s in range(4)], disp_d, rgb0, [means[s] for s in range(4)], pose_d, d0, d1,
                       t(sample_w), t(smooth_w) if n_smooth else None, losses, aux if n_smooth else None, B, nblk, H, W,
                       n_smooth, 1e-3, 0.05)
-    out = dict(T=T, P=P, depth=depth, warped=warped, losses=losses, sel=sel)
+    out = dict(T=T, P=P, depth=depth, warped=warped, losses=losses, sel=sel, partial=partial)
     if not train:
         return out
     dz = []
@@ -63,10 +67,12 @@ def _run_loss_stage(dev, inputs, disp, pose, noise, sample_w, smooth_w, H, W, mi
         nb2 = ops.loss_bwd2_blocks(H, W)
         dp_partial = torch.empty(4, B, nb2, 24, dtype=torch.float64, device=dev)
         ddisp_all = torch.empty(4, B, H, W, device=dev)
-        ops.loss_bwd2_pyramid(disp_d, sel, coef_sel, warped, src[0], src[-1], src[1], Kinv, P, t(sample_w), ddisp_all, dp_partial,
-                              min_depth, max_depth)
+        for r in ranges:
+            ops.loss_bwd2_pyramid(disp_d, sel, coef_sel, warped, src[0], src[-1], src[1], Kinv, P, t(sample_w), ddisp_all, dp_partial,
+                                  min_depth, max_depth, scales=r)
         dz = [torch.empty_like(d) for d in disp_d]
-        ops.disp_grad_pyramid(ddisp_all, disp_d, aux if n_smooth else None, n_smooth, dz, H, W)
+        for r in ranges:
+            ops.disp_grad_pyramid(ddisp_all, disp_d, aux if n_smooth else None, n_smooth, dz, H, W, scales=r)
     else:
         nb2 = ops.warp_bwd_blocks(H, W)
         dp_partial = torch.empty(4, B, nb2, 24, dtype=torch.float64, device=dev)
@@ -214,3 +220,27 @@ def test_in_kernel_tie_break_noise(backend):
         outs.append((sel.cpu(), partial.cpu(), coef.cpu()))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
     assert not torch.equal(outs[0][0], outs[2][0])                                 # the noise does decide near-ties
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_per_scale_launches_write_what_the_pyramid_launch_writes(backend):
+    """clslam_*_pyramid_range: scales 3, 2, 1, 0 as four launches of the view synthesis, the photometric stage, the loss backward
+    and the disparity-logit gradient give bit for bit the one-launch results (the engine issues the coarse scales beside the
+    depth decoder in steps 2..S of adapt(steps=S))."""
+    dev = use_backend(backend)
+    B, H, W = 2, 32, 64
+    inputs = synth.make_batch(B, H, W, seed=6)
+    noise = synth.make_noise(B, H, W, seed=3)
+    g = torch.Generator().manual_seed(8)
+    disp = [torch.sigmoid(torch.randn(B, H >> s, W >> s, generator=g) * 0.5) for s in range(4)]
+    pose = torch.randn(2 * B, 12, generator=g) * 0.01
+    sw = torch.ones(B) / B
+    a = _run_loss_stage(dev, inputs, disp, pose, noise, sw, sw, H, W, 0.1, None, train=True, pyramid=True)
+    b = _run_loss_stage(dev, inputs, disp, pose, noise, sw, sw, H, W, 0.1, None, train=True, pyramid='split')
+    for k in ('depth', 'warped', 'losses', 'sel', 'partial', 'dpose'):
+        assert torch.equal(a[k], b[k]), k
+    for s in range(4):
+        assert torch.equal(a['dz'][s], b['dz'][s]), s
+    with pytest.raises(Exception, match='outside the pyramid'):
+        ops.warp_fwd_pyramid([d.to(dev) for d in disp], a['warped'][0, 0], a['warped'][0, 0], a['T'][0], a['P'], a['depth'], a['warped'],
+                             0.1, None, scales=(3, 2))
