@@ -46,7 +46,10 @@ def test_gradients_match_oracle_and_the_residual_is_selection_flips(backend, cap
     r = _run(backend, 64, 128, 2, seed=3)
     with capsys.disabled():
         report_attribution(f'{backend} 64x128 B=2', r)
-    assert r['flips'] <= 2e-4 * r['npix'] and r['gap'] < 5e-6, (r['flips'], r['gap'])
+    # a selection may only differ where the two candidates are closer than the photometric value can differ between the two
+    # paths: the sampling positions agree to 2e-5 px (tests/test_warp_positions.py) and the synthetic frames change by <= ~1 per
+    # pixel, so 2e-5 (measured: 4e-6 ... 9e-6 depending on the summation order of the decoder's launches)
+    assert r['flips'] <= 2e-4 * r['npix'] and r['gap'] < 2e-5, (r['flips'], r['gap'])
     assert r['cell_flips'] + r['clip_flips'] <= 1e-3 * r['npix']
     rows = r['rows']
     for name, e_free, e_forced, norm, e_all, e_hip64, e_o64, e_bwd, e_bwd_t32, e_bwd_p, e_bwd_p_t32 in rows:

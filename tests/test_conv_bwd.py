@@ -83,7 +83,7 @@ def test_conv_backward_matches_autograd(case, backend):
         dw = torch.empty(n, device=dev)
         ops.reduce_partials(partial, dw, n, splits)
         assert rel_err(dw.cpu().view_as(w), w.grad) < 2e-5, (target, splits)
-    if k == 3 and Ca % 32 == 0 and Cb % 32 == 0 and Cout % 32 == 0 and (W, H % 4) == (40, 0) or (H, W) == (6, 20):
+    if k == 3 and Ca % 32 == 0 and Cb % 32 == 0 and Cout % 32 == 0 and ((W, H % 4) == (40, 0) or (H, W) == (6, 20)):
         assert ops.wgrad_patch_supported(desc)          # the deep-stage tiles are on in this file
     if ops.wgrad_patch_supported(desc):
         for target in (1, 16):

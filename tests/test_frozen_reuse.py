@@ -31,10 +31,15 @@ def _run(B: int, reuse: bool, inject_noise: bool, H: int, W: int, plan=(3, 2)):
 
 
 @pytest.mark.parametrize('backend', BACKENDS)
-@pytest.mark.parametrize('B', [2, 3])               # B=2 forces the hipGraph path on the GPU, B=3 the eager one
+@pytest.mark.parametrize('B', [2, 3, 4])            # B=2 forces the hipGraph path on the GPU, B=3 the eager one, B=4 the eager one
+                                                    # with the opt-in early coarse-scale loss schedule (engine.early_loss)
 def test_frozen_feature_reuse_is_bitwise_invisible(backend, B, monkeypatch):
     if B == 2:
         monkeypatch.setenv('CLSLAM_HIPGRAPH', '1')   # opt-in path: its encoder-free second graph is covered here
+    if B == 4:
+        if backend != 'hip':
+            pytest.skip('the early schedule needs the side streams')
+        monkeypatch.setenv('CLSLAM_EARLY_LOSS', '1')
     if backend != 'hip' and B == 3:
         pytest.skip('eager path already covered by B=2 on the emulator')
     use_backend(backend)
