@@ -807,32 +807,41 @@ __global__ __launch_bounds__(256) void disp_grad_coop_kernel(const float* __rest
     const int idx = live ? t / G : 0, q = t % G;
     const int qy = q / f, qx = q % f;
     const int j = idx % w, i = (idx / w) % h, b = idx / (w * h);
+    // The four taps and the disparity are requested together from clamped (always valid) addresses and weighted afterwards, in
+    // the order of the loop they replace (a tap outside the image contributes an exact 0): with `continue` per tap every load
+    // sat behind an `s_waitcnt vmcnt(0)` of its own -- five serial round trips on the step's critical chain (round 5).
     float g = 0.f;
-    if (live) {
+    float wgt[4], val[4];
+    const float dsp = disp[idx];
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            const int Y = f * i - f / 2 + qy + a * f;
-            if (Y < 0 || Y >= H) continue;
-            float sy = ry * ((float)Y + 0.5f) - 0.5f; if (sy < 0.f) sy = 0.f;
-            const int y0 = (int)sy, y1 = y0 + (y0 < h - 1 ? 1 : 0);
-            const float ly = sy - (float)y0;
-            float wy = 0.f;
-            if (y0 == i) wy += 1.f - ly;
-            if (y1 == i) wy += ly;
+    for (int a = 0; a < 2; ++a) {
+        const int Y = f * i - f / 2 + qy + a * f;
+        const bool oky = Y >= 0 && Y < H;
+        const int Yc = min(max(Y, 0), H - 1);
+        float sy = ry * ((float)Yc + 0.5f) - 0.5f; if (sy < 0.f) sy = 0.f;
+        const int y0 = (int)sy, y1 = y0 + (y0 < h - 1 ? 1 : 0);
+        const float ly = sy - (float)y0;
+        float wy = 0.f;
+        if (y0 == i) wy += 1.f - ly;
+        if (y1 == i) wy += ly;
 #pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                const int X = f * j - f / 2 + qx + c * f;
-                if (X < 0 || X >= W) continue;
-                float sx = rx * ((float)X + 0.5f) - 0.5f; if (sx < 0.f) sx = 0.f;
-                const int x0 = (int)sx, x1 = x0 + (x0 < w - 1 ? 1 : 0);
-                const float lx = sx - (float)x0;
-                float wx = 0.f;
-                if (x0 == j) wx += 1.f - lx;
-                if (x1 == j) wx += lx;
-                g += wy * wx * ddisp_up[((size_t)b * H + Y) * W + X];
-            }
+        for (int c = 0; c < 2; ++c) {
+            const int X = f * j - f / 2 + qx + c * f;
+            const bool okx = X >= 0 && X < W;
+            const int Xc = min(max(X, 0), W - 1);
+            float sx = rx * ((float)Xc + 0.5f) - 0.5f; if (sx < 0.f) sx = 0.f;
+            const int x0 = (int)sx, x1 = x0 + (x0 < w - 1 ? 1 : 0);
+            const float lx = sx - (float)x0;
+            float wx = 0.f;
+            if (x0 == j) wx += 1.f - lx;
+            if (x1 == j) wx += lx;
+            wgt[a * 2 + c] = (live && oky && okx) ? wy * wx : 0.f;
+            val[a * 2 + c] = ddisp_up[((size_t)b * H + Yc) * W + Xc];
         }
     }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (wgt[k] != 0.f) g += wgt[k] * val[k];      // (a select, not a branch: same sum as the taps that were visited)
     for (int m = 1; m < G; m <<= 1) g += wave_shfl_xor(g, m);   // G <= 64 lanes of one wave, aligned
     if (live && q == 0) {
         if (n_smooth > 0 && b == 0) {
@@ -848,7 +857,7 @@ __global__ __launch_bounds__(256) void disp_grad_coop_kernel(const float* __rest
             }
             g += inv0 * D - fb;
         }
-        const float d = disp[idx];
+        const float d = dsp;
         dz[idx] = g * d * (1.f - d);
     }
 }

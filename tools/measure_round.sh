@@ -57,7 +57,11 @@ BENCH_WGRAD=0 python tools/bench_conv.py 1 30,31,32,33 > $OUT/${TAG}_conv_microb
 # Winograd F(2x2,3x3) (config 40) against the library's direct pick on the encoder layer shapes, B = 5 / 10 / 33
 { for b in 5 10 33; do echo "== B = $b"; BENCH_WGRAD=0 BENCH_LAYERS=0,1,2,3,8 python tools/bench_conv.py $b 40 2>&1 | grep -v amdgpu; done; } > $OUT/${TAG}_wino_microbench.txt
 # gfx950 calibration the kernel designs rest on: MFMA vs same-wave / partner-wave VALU, LDS-DMA rate per CU
-{ for m in mfma_clock mfma_valu_share lds_dma_rate; do echo "== tools/micro/$m.hip"; hipcc --offload-arch=gfx950 -O3 -o /tmp/$m tools/micro/$m.hip 2>/dev/null && /tmp/$m; done; } > $OUT/${TAG}_micro_calibration.txt 2>&1
+{ for m in mfma_clock mfma_valu_share lds_dma_rate event_gap ext_launch_cost; do echo "== tools/micro/$m.hip"; hipcc --offload-arch=gfx950 -O3 -o /tmp/$m tools/micro/$m.hip 2>/dev/null && /tmp/$m; done; } > $OUT/${TAG}_micro_calibration.txt 2>&1
+# one decoder-only step (steps 2..5 of adapt(steps=5)) as a kernel timeline
+rm -rf /tmp/prof_s5
+(cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/prof_s5 -o run -- python $OLDPWD/bench.py --adapt-steps 5 --steps 6 --warmup 2 --blocks 1 --no-also --no-cpu-baseline > /tmp/prof_s5.log 2>&1)
+python tools/timeline.py $(ls /tmp/prof_s5/*/*.db /tmp/prof_s5/*.db 2>/dev/null | head -1) -14 > $OUT/${TAG}_timeline_reuse_step.txt 2>&1
 python tools/bench_small.py > $OUT/${TAG}_small_kernels.txt 2>&1
 python tools/bench_reduce.py > $OUT/${TAG}_reduce.txt 2>&1
 BENCH_DGRAD=1 BENCH_WGRAD=0 python tools/bench_conv.py 5 20,21,22,26,30,31,32,33 2>&1 | grep -v amdgpu > $OUT/${TAG}_conv_microbench_dgrad.txt
