@@ -174,10 +174,36 @@ def set_conv_workspace(stream_handle: int, workspace: Optional[torch.Tensor]) ->
 PERSISTENT_CU_LIMIT = 0
 
 
+# Descriptors of the engine's fixed call sites (conv2d(..., key=...)): the same layer on the same workspace buffers every step.
+# Building the 28-field ctypes structure costs 2.2 of the 5.8 us a conv2d() call takes on the MI355X box's host; a single-triplet
+# step (75 convolutions, host-bound) pays that 75 times.  An entry is re-used only while the three tensors that can change under
+# a call site (source, weight, output) still sit where they sat; everything else of a site is fixed by construction.
+_CONV_DESC_CACHE: dict = {}
+_DESC_CACHE_ON = __import__('os').environ.get('CLSLAM_DESC_CACHE', '1') != '0'
+
+
 def conv2d(src_a, weight, out, *, src_b=None, scale=None, shift=None, residual=None, ksize=3, stride=1,
            pad=None, pad_mode=PAD_ZERO, upsample_a=False, act=ACT_NONE, config=-1, actgrad_src=None,
-           actgrad_kind=ACT_NONE, workspace=None, weight_wino=None, cu_limit=None):
-    """src_a (B,Ha,Wa,Ca) NHWC; weight (Cout, k*k, Ca+Cb); out (B,Ho,Wo,Cout); weight_wino: wino_weight_transform(weight)."""
+           actgrad_kind=ACT_NONE, workspace=None, weight_wino=None, cu_limit=None, key=None):
+    """src_a (B,Ha,Wa,Ca) NHWC; weight (Cout, k*k, Ca+Cb); out (B,Ho,Wo,Cout); weight_wino: wino_weight_transform(weight).
+    key (hashable, optional): identifies a FIXED call site -- same layer, same buffers, same keyword arguments every time;
+    its descriptor is kept and only stream-dependent fields (split-K scratch, cu_limit) are refreshed."""
+    if key is not None and PROFILE is None and _DESC_CACHE_ON:
+        ent = _CONV_DESC_CACHE.get(key)
+        if ent is not None:
+            d, ref, lib = ent
+            if d.src_a == src_a.data_ptr() and d.out == out.data_ptr() and d.weight == weight.data_ptr():
+                stream = _stream(out)
+                ws = workspace if workspace is not None else (_CONV_WORKSPACES.get(stream) if _CONV_WORKSPACES else None)
+                if ws is None:
+                    d.workspace, d.workspace_bytes = None, 0
+                else:
+                    d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
+                d.cu_limit = PERSISTENT_CU_LIMIT if cu_limit is None else cu_limit
+                rc = lib.cdll.clslam_conv2d(ref, stream)
+                if rc != _lib.OK:
+                    raise _lib.ClslamError(f'clslam_conv2d failed ({rc}): {lib.cdll.clslam_last_error().decode()}')
+                return out
     B, Ho, Wo, Cout = out.shape
     Ha, Wa, Ca = src_a.shape[1:]
     Hi, Wi = (Ha * 2, Wa * 2) if upsample_a else (Ha, Wa)
@@ -200,7 +226,10 @@ def conv2d(src_a, weight, out, *, src_b=None, scale=None, shift=None, residual=N
                         (0 if residual is None else residual.numel()) + (0 if actgrad_src is None else actgrad_src.numel()))
         PROFILE.append(('conv', cfg, 2.0 * B * Ho * Wo * Cout * ksize * ksize * (Ca + Cb),
                         f'B{B} {Hi}x{Wi} {Ca}+{Cb}->{Cout} k{ksize} s{stride} pad{pad}', nbytes))
-    _lib.get_lib().call('clslam_conv2d', C.byref(d), stream)
+    lib = _lib.get_lib()
+    lib.call('clslam_conv2d', C.byref(d), stream)
+    if key is not None and PROFILE is None:
+        _CONV_DESC_CACHE[key] = (d, C.byref(d), lib)
     return out
 
 
