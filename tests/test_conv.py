@@ -281,3 +281,31 @@ def test_conv2d_winograd(backend, case, config, monkeypatch):
     with pytest.raises(Exception, match='weight_wino'):
         ops.conv2d(t(x), t(w), out, ksize=3, pad=pad, config=config, workspace=ws)
 
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_conv2d_call_site_descriptor_cache(backend):
+    """conv2d(..., key=...): a fixed call site's descriptor is re-used only while source, weight and output sit where they sat --
+    another tensor under the same key gets a descriptor of its own, the result is the uncached call's every time."""
+    dev = use_backend(backend)
+    g = torch.Generator().manual_seed(5)
+    w = (torch.randn(16, 9, 16, generator=g) / 12).to(dev)
+    b = torch.randn(16, generator=g).to(dev)
+    key = ('test-site', backend)
+    ops._CONV_DESC_CACHE.pop(key, None)
+    xs = [torch.randn(1, 8, 16, 16, generator=g).to(dev) for _ in range(2)]
+    for rnd in range(3):
+        for x in xs:                      # the SAME key sees two different sources (and fresh outputs): validated, not trusted
+            ref = torch.empty(1, 8, 16, 16, device=dev)
+            ops.conv2d(x, w, ref, shift=b, ksize=3, act=2)
+            out = torch.full((1, 8, 16, 16), float('nan'), device=dev)
+            ops.conv2d(x, w, out, shift=b, ksize=3, act=2, key=key)
+            assert torch.equal(out, ref)
+            out2 = out.clone().fill_(float('nan'))
+            d_before = ops._CONV_DESC_CACHE[key][0]
+            ops.conv2d(x, w, out2, shift=b, ksize=3, act=2, key=key)      # other output buffer: rebuilt
+            assert torch.equal(out2, ref) and ops._CONV_DESC_CACHE[key][0] is not d_before
+            d_before = ops._CONV_DESC_CACHE[key][0]
+            out2.fill_(float('nan'))
+            ops.conv2d(x, w, out2, shift=b, ksize=3, act=2, key=key)      # same three tensors: the kept descriptor
+            assert torch.equal(out2, ref) and ops._CONV_DESC_CACHE[key][0] is d_before
