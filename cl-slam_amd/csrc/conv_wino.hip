@@ -186,7 +186,11 @@ __global__ __launch_bounds__(512) void conv3x3_wino8_kernel(WinoK p) {
     const int t_hi = (int)((u1 - 1) / p.NS);
 
     // ---- compute-side constants: this lane's operand slot is input channels 2*kg, 2*kg+1 of a stage -------------------------
-    const int urow = (wn * 32 + li) * 8 + (((kg >> 1) ^ ((li >> 3) & 1)) << 2) + ((kg & 1) << 1);     // + nt * 128 + pos * 512
+    // U of a stage in LDS: [16 positions][4 groups of 16 output channels][4 input-channel pairs][16 channels][2] -- the 32 lanes the
+    // LDS serves per pass of a ds_read_b64 (li = 0..15 of two channel pairs) read two contiguous 128-byte rows.  (Rounds 5's first
+    // layout, [channel][8 input channels] rows of 32 bytes with the 16-byte halves swizzled, put channels li and li + 4 of a pass on
+    // the same banks: SQ_LDS_BANK_CONFLICT = 50 % of the U reads' LDS-active cycles, tools/wino_lds_probe.sh.)
+    const int urow = wn * 256 + kg * 32 + li * 2;     // + nt * 128 + pos * 512
     int raddr[16];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
@@ -431,30 +435,31 @@ __global__ __launch_bounds__(512) void conv3x3_wino8_kernel(WinoK p) {
 __global__ void wino_weight_transform_kernel(const float* __restrict__ w, float* __restrict__ u, int Cout, int Cin, int tilesN, int NS) {
     const size_t total = (size_t)tilesN * NS * (kWinoUFloats / 4);
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        const int pslot = (int)(idx & 1);
-        const int nl = (int)((idx >> 1) & 63);
+        // float4 `idx` of the LDS image: [block = (channel tile, stage)][pos 16][channel group 4][input-channel pair 4][8 float4], a
+        // float4 = (channel n0: c0, c1)(channel n0 + 1: c0, c1)
+        const int r = (int)(idx & 127);
         const int pos = (int)((idx >> 7) & 15);
         const size_t blk = idx >> 11;
         const int s = (int)(blk % NS), tn = (int)(blk / NS);
-        const int ls = pslot ^ ((nl >> 3) & 1);
-        const int n = tn * 64 + nl, i = pos >> 2, j = pos & 3;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (n < Cout) {
-            float o[4];
-            for (int e = 0; e < 4; ++e) {
-                const int c = s * 8 + ls * 4 + e;
+        const int cp = (r & 31) >> 3, n0 = tn * 64 + (r >> 5) * 16 + (r & 7) * 2;
+        const int i = pos >> 2, j = pos & 3;
+        float o[4];
+        for (int e = 0; e < 4; ++e) {
+            const int n = n0 + (e >> 1), c = s * 8 + cp * 2 + (e & 1);
+            o[e] = 0.f;
+            if (n < Cout) {
                 double g[3][3];
                 for (int a = 0; a < 3; ++a)
                     for (int b = 0; b < 3; ++b) g[a][b] = (double)w[((size_t)n * 9 + a * 3 + b) * Cin + c];
                 // rows of G: (1,0,0), (1/2,1/2,1/2), (1/2,-1/2,1/2), (0,0,1)
-                double r[3];
+                double rr[3];
                 for (int b = 0; b < 3; ++b)
-                    r[b] = i == 0 ? g[0][b] : i == 1 ? 0.5 * (g[0][b] + g[1][b] + g[2][b]) : i == 2 ? 0.5 * (g[0][b] - g[1][b] + g[2][b]) : g[2][b];
-                const double val = j == 0 ? r[0] : j == 1 ? 0.5 * (r[0] + r[1] + r[2]) : j == 2 ? 0.5 * (r[0] - r[1] + r[2]) : r[2];
+                    rr[b] = i == 0 ? g[0][b] : i == 1 ? 0.5 * (g[0][b] + g[1][b] + g[2][b]) : i == 2 ? 0.5 * (g[0][b] - g[1][b] + g[2][b]) : g[2][b];
+                const double val = j == 0 ? rr[0] : j == 1 ? 0.5 * (rr[0] + rr[1] + rr[2]) : j == 2 ? 0.5 * (rr[0] - rr[1] + rr[2]) : rr[2];
                 o[e] = (float)val;
             }
-            v = make_float4(o[0], o[1], o[2], o[3]);
         }
+        const float4 v = make_float4(o[0], o[1], o[2], o[3]);
         reinterpret_cast<float4*>(u)[idx] = v;
     }
 }
