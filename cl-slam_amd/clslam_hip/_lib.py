@@ -165,6 +165,15 @@ class Library:
                 '(hipcc --offload-arch=gfx950). There is no CPU fallback for this path.')
         self.path = Path(path)
         self.cdll = C.CDLL(str(path))
+        # the version FIRST: a stale library lacks the newer entry points, and resolving those before the check would end in an
+        # AttributeError about one symbol instead of the instruction to rebuild
+        try:
+            got = int(self.cdll.clslam_version())
+        except AttributeError:
+            raise ClslamError(f'{path} does not export clslam_version: not a clslam kernel library') from None
+        if got != ABI_VERSION:      # a stale library would read the descriptors with another layout: refuse instead of corrupting memory
+            raise ClslamError(f'{path} implements ABI version {got}, this binding needs {ABI_VERSION}: rebuild it with '
+                              '`python cl-slam_amd/csrc/build.py`')
         for name, rt in _RESTYPES.items():
             fn = getattr(self.cdll, name)
             fn.restype, fn.argtypes = rt, []
@@ -181,10 +190,6 @@ class Library:
             fn = getattr(self.cdll, name)  # AttributeError if the symbol is not exported
             fn.argtypes = argtypes
             fn.restype = C.c_int
-        got = int(self.cdll.clslam_version())
-        if got != ABI_VERSION:      # a stale library would read the descriptors with another layout: refuse instead of corrupting memory
-            raise ClslamError(f'{path} implements ABI version {got}, this binding needs {ABI_VERSION}: rebuild it with '
-                              '`python cl-slam_amd/csrc/build.py`')
         self.is_device = bool(self.cdll.clslam_is_device_build())
         if require_device and not self.is_device:
             raise ClslamError(f'{path} is not a gfx950 device build')

@@ -113,7 +113,9 @@ extern "C" void clslam_handoff_event_destroy(void* event) {
 
 extern "C" int clslam_handoff_arm(void* event) {
     CLSLAM_REQUIRE(event, "handoff_arm: null event");
-    CLSLAM_REQUIRE(clslam::g_handoff == nullptr, "handoff_arm: an armed event has not been waited on (clslam_handoff_wait)");
+    // An event still armed here was armed for a launch that never went out (the call between arm and wait failed its argument
+    // checks) and was never recorded: it is dropped, nobody waits for it.  Refusing instead left the host thread
+    // unable to arm ever again after one recoverable error.
     clslam::g_handoff = (hipEvent_t)event;
     return CLSLAM_OK;
 }

@@ -35,6 +35,7 @@
 // wave's transform / LDS reads / DMA issue run while its partner on the SIMD holds the matrix pipe: 60-111 TFLOP/s
 // (profiles/r05_wino_microbench.txt), and the kernel needs no inline-asm register file.
 #include "common.h"
+#include <type_traits>
 
 
 namespace clslam {
@@ -45,7 +46,7 @@ int sk_device_cus();
 __device__ float g_wino_zero_page[64];   // DMA source of padded / out-of-range patch rows
 
 constexpr int kWinoFlagOffset = 8192;          // = kSkFlagOffset
-constexpr int kWinoMaxGroups = 4096;
+constexpr int kWinoMaxGroups = 1024;          // 8 hand-off flags (one per wave) per workgroup in the 8192-entry flag region
 constexpr int kWinoSlabOffsetBytes = 64 << 10;
 constexpr unsigned kWinoSpinLimit = 1u << 22;
 constexpr int kWinoPP = 352;                   // patch rows (pixels) per 16-channel chunk buffer
@@ -78,14 +79,14 @@ struct WinoK {
 #endif
 constexpr int kWinoDbg = CLSLAM_WINO_DBG;
 // -DCLSLAM_WINO_TRACE=1: thread 0 of every workgroup stamps s_memtime at its phase boundaries into the workspace behind the slabs
-// ([G][64] u64: start, prologue transfers landed, prologue done, then per unit: MFMA loop done, finish done, barrier passed)
+// ([G][64] u64: start, prologue done (twice), then per unit: MFMA loop done, finish done, barrier passed)
 #ifndef CLSLAM_WINO_TRACE
 #define CLSLAM_WINO_TRACE 0
 #endif
 
+
 __global__ __launch_bounds__(512) void conv3x3_wino8_kernel(WinoK p) {
     __shared__ __attribute__((aligned(1024))) float lds[2 * kWinoPatchFloats + 3 * kWinoUFloats];      // 140 KiB
-    __shared__ int s_flag_ok;
     float* const Pbuf = lds;
     float* const Ubuf = lds + 2 * kWinoPatchFloats;
 
@@ -107,8 +108,12 @@ __global__ __launch_bounds__(512) void conv3x3_wino8_kernel(WinoK p) {
 #endif
     const long long u0 = (long long)grp * p.units / p.G, u1 = (long long)(grp + 1) * p.units / p.G;
     if (u0 >= u1) return;
-    if (tid == 0) s_flag_ok = 1;
-#if CLSLAM_WINO_TRACE && CLSLAM_DEVICE_BUILD
+#if CLSLAM_WINO_TRACE >= 3 && CLSLAM_DEVICE_BUILD
+    // per-WAVE stamps ([G][8 waves][64] u64): start, prologue done, then per unit: input transform done, 16 positions done, finish()
+    // done, DMA wait done, barrier passed (tools/wino_trace_waves.py)
+    int n_stamp = 0;
+    auto stamp = [&]() { if (lane == 0 && n_stamp < 64) p.trace[((size_t)grp * 8 + wave) * 64 + n_stamp] = __builtin_amdgcn_s_memtime(); ++n_stamp; };
+#elif CLSLAM_WINO_TRACE && CLSLAM_DEVICE_BUILD
     int n_stamp = 0;
     auto stamp = [&]() { if (tid == 0 && n_stamp < 64) p.trace[(size_t)grp * 64 + n_stamp] = __builtin_amdgcn_s_memtime(); ++n_stamp; };
 #else
@@ -121,9 +126,14 @@ __global__ __launch_bounds__(512) void conv3x3_wino8_kernel(WinoK p) {
     const int rtiles = p.RH * p.RW;
     const bool tile_valid = q < p.RB * rtiles;
     const int qq = tile_valid ? q : 0;
-    const int t_bl = qq / rtiles, t_ty = (qq - t_bl * rtiles) / p.RW, t_tx = qq - t_bl * rtiles - t_ty * p.RW;
     const int PW = 2 * p.RW + 2, PH = 2 * p.RH + 2;
-    const int prow0 = (t_bl * PH + 2 * t_ty) * PW + 2 * t_tx;
+    int tile_pos;            // (image, tile row, tile column) of the lane's tile inside the region, ONE register across the unit loop
+    int prow0;
+    {
+        const int t_bl = qq / rtiles, t_ty = (qq - t_bl * rtiles) / p.RW, t_tx = qq - t_bl * rtiles - t_ty * p.RW;
+        prow0 = (t_bl * PH + 2 * t_ty) * PW + 2 * t_tx;
+        tile_pos = (t_bl << 20) | (t_ty << 10) | t_tx;
+    }
 
     auto decode_tile = [&](int t, int& tn, int& rx, int& ry, int& rb) {
         if (p.b_fastest) {
@@ -143,6 +153,19 @@ __global__ __launch_bounds__(512) void conv3x3_wino8_kernel(WinoK p) {
     const int dls = (lane & 3) ^ ((drow >> 2) & 3);
     int offP[MYP];
     int dma_tile = -1, dma_tn = 0;
+    // which pixel of the region's patch a lane's DMA row is (image, Y, X packed; -1: beyond the patch) does not depend on the tile:
+    // decomposed ONCE (two integer divisions per piece on the VALU, ~250 instructions a tile change cost before)
+    int prc[MYP];
+#pragma unroll
+    for (int k = 0; k < MYP; ++k) {
+        const int row = (wave + 8 * k) * 16 + drow;
+        prc[k] = -1;
+        if (wave + 8 * k < NPP && row < p.RB * PH * PW) {
+            const int bl = row / (PH * PW), r2 = row - bl * (PH * PW);
+            const int Y = r2 / PW, X = r2 - Y * PW;
+            prc[k] = (bl << 20) | (Y << 10) | X;
+        }
+    }
     auto dma_setup_tile = [&](int t) {
         int tn, rx, ry, rb;
         decode_tile(t, tn, rx, ry, rb);
@@ -150,14 +173,9 @@ __global__ __launch_bounds__(512) void conv3x3_wino8_kernel(WinoK p) {
         const int y0 = ry * 2 * p.RH - p.pad, x0 = rx * 2 * p.RW - p.pad;
 #pragma unroll
         for (int k = 0; k < MYP; ++k) {
-            const int row = (wave + 8 * k) * 16 + launder(drow);
-            offP[k] = -1;
-            if (wave + 8 * k < NPP && row < p.RB * PH * PW) {
-                const int bl = row / (PH * PW), r2 = row - bl * (PH * PW);
-                const int Y = r2 / PW, X = r2 - Y * PW;
-                const int b = rb * p.RB + bl, iy = y0 + Y, ix = x0 + X;
-                if (b < p.B && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi) offP[k] = ((b * p.Hi + iy) * p.Wi + ix) * p.Cin;
-            }
+            const int c = launder(prc[k]);
+            const int b = rb * p.RB + (c >> 20), iy = y0 + ((c >> 10) & 1023), ix = x0 + (c & 1023);
+            offP[k] = (c >= 0 && b < p.B && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi) ? ((b * p.Hi + iy) * p.Wi + ix) * p.Cin : -1;
         }
     };
     auto dma_patch_piece = [&](int k, int chunk, int pbuf) {
@@ -191,13 +209,15 @@ __global__ __launch_bounds__(512) void conv3x3_wino8_kernel(WinoK p) {
     // layout, [channel][8 input channels] rows of 32 bytes with the 16-byte halves swizzled, put channels li and li + 4 of a pass on
     // the same banks: SQ_LDS_BANK_CONFLICT = 50 % of the U reads' LDS-active cycles, tools/wino_lds_probe.sh.)
     const int urow = wn * 256 + kg * 32 + li * 2;     // + nt * 128 + pos * 512
-    int raddr[16];
+    // LDS BYTE offsets of the lane's 4x4 raw pixels inside a patch buffer; the address of a read is (offset ^ half) + buffer: one
+    // v_xad_u32 (as float indices it took a v_bitop3 and a v_lshl_add per read)
+    unsigned raddr[16];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
             const int r = prow0 + a * PW + b;
-            raddr[a * 4 + b] = r * 16 + (((kg >> 1) ^ ((r >> 2) & 3)) << 2) + ((kg & 1) << 1);
+            raddr[a * 4 + b] = (unsigned)(r * 16 + (((kg >> 1) ^ ((r >> 2) & 3)) << 2) + ((kg & 1) << 1)) * 4u;
         }
 
     f32x4 acc[16][2];
@@ -211,224 +231,254 @@ __global__ __launch_bounds__(512) void conv3x3_wino8_kernel(WinoK p) {
     };
     zero_acc();
 
-    auto load_raw = [&](const float* Ps, int half, float2 (&R)[16]) {
+    auto load_raw = [&](int pbuf, int half, f32x2 (&R)[16]) {
+        unsigned base = (unsigned)(pbuf * kWinoPatchFloats) * 4u, hx = (unsigned)half << 5;
+        // opaque values, one in a scalar and one in a vector register (a VALU instruction reads one SGPR): v_xad_u32 per read;
+        // hipcc folds the masks into a v_bitop3 + v_add per read otherwise
+        launder_uniform(hx);
+        base = (unsigned)launder((int)base);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) R[i] = *reinterpret_cast<const float2*>(&Ps[raddr[i] ^ (half << 3)]);
+        for (int i = 0; i < 16; ++i) R[i] = lds_read_f32x2(lds, lds0, (raddr[i] ^ hx) + base);
     };
-    auto sub2 = [](float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); };
-    auto add2 = [](float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); };
-    // B^T d B in place, sixteen halves of two float2 operations: column pass over the rows of d (slices 0-3), row pass (4-7)
-    float2 tf_mid;
-    auto transform_half = [&](float2 (&R)[16], int hs) __attribute__((always_inline)) {
+    // B^T d B in place on packed pairs (v_pk_add_f32: the lane's two input channels per instruction), sixteen halves of two
+    // operations: column pass over the rows of d (slices 0-3), row pass (4-7)
+    f32x2 tf_mid;
+    auto transform_half = [&](f32x2 (&R)[16], int hs) __attribute__((always_inline)) {
         const int sl = hs >> 1;
         const int i0 = sl < 4 ? sl : (sl - 4) * 4, st = sl < 4 ? 4 : 1;
         if ((hs & 1) == 0) {
             tf_mid = R[i0 + st];
-            R[i0] = sub2(R[i0], R[i0 + 2 * st]); R[i0 + st] = add2(tf_mid, R[i0 + 2 * st]);
+            R[i0] = R[i0] - R[i0 + 2 * st]; R[i0 + st] = tf_mid + R[i0 + 2 * st];
         } else {
-            const float2 d2 = R[i0 + 2 * st];
-            R[i0 + 2 * st] = sub2(d2, tf_mid); R[i0 + 3 * st] = sub2(tf_mid, R[i0 + 3 * st]);
+            const f32x2 d2 = R[i0 + 2 * st];
+            R[i0 + 2 * st] = d2 - tf_mid; R[i0 + 3 * st] = tf_mid - R[i0 + 3 * st];
         }
     };
 
     // ---- end of a region segment ----------------------------------------------------------------------------------------
-    bool publish_pending = false;
+    // finish() of a partial segment marks the wave's flag for publication: it goes out at the wave's next-but-one DMA wait
+    bool publish_pending = false, publish_armed = false;
     auto finish = [&](int t, int s_lo, int s_hi) __attribute__((always_inline)) -> bool {
         const bool owner = s_hi == p.NS;
         if ((kWinoDbg & 2) && (!owner || s_lo > 0)) return false;
         int ncon = 0;
         float poison = 0.f;
         if (owner && s_lo > 0) {
+            // Hand-offs are per WAVE: wave w of the owner adds exactly the slab rows wave w of a contributor wrote, so every wave
+            // waits for its own eight flags and no workgroup barrier sits inside finish() (the two wave groups of a workgroup
+            // reach it half a unit apart).  Flags hold the launch's epoch: nothing has to be reset.
             const long long tile_first = (long long)t * p.NS;
             for (int g2 = grp - 1; g2 >= 0 && (long long)(g2 + 1) * p.units / p.G > tile_first; --g2) ++ncon;
-            for (int c = tid; c < ncon; c += 512) {
+            float bad = 0.f;
+            for (int c = lane; c < ncon; c += 64) {
                 unsigned spins = 0;
-                while (coherent_load_u32(&p.flags[grp - 1 - c]) != p.epoch && ++spins < kWinoSpinLimit) spin_pause();
-                if (spins >= kWinoSpinLimit) s_flag_ok = 0;
-                uncounted_flag_store(&p.flags[grp - 1 - c], 0u);
+                while (coherent_load_u32(&p.flags[(grp - 1 - c) * 8 + wave]) != p.epoch && ++spins < kWinoSpinLimit) spin_pause();
+                if (spins >= kWinoSpinLimit) bad = 1.f;
             }
-            __syncthreads();
-            poison = s_flag_ok ? 0.f : __builtin_nanf("");
+            poison = wave_sum(bad) > 0.f ? __builtin_nanf("") : 0.f;
         }
-        if (CLSLAM_WINO_TRACE > 1) stamp();      // flags seen
+        if (CLSLAM_WINO_TRACE == 2) stamp();      // flags seen
         int tn, rx, ry, rb;
         decode_tile(t, tn, rx, ry, rb);
-        const int b = rb * p.RB + t_bl;
-        const int oy = (ry * p.RH + t_ty) * 2, ox = (rx * p.RW + t_tx) * 2;
+        const int tp = launder(tile_pos);
+        const int b = rb * p.RB + (tp >> 20);
+        const int oy = (ry * p.RH + ((tp >> 10) & 1023)) * 2, ox = (rx * p.RW + (tp & 1023)) * 2;
         const int nbase = tn * 64 + wn * 32 + 4 * kg;            // + 16 * nt
         const bool has_res = p.residual != nullptr;
-        // epilogue operands first: their round trip hides behind the output transform
-        float4 sc[2], sh[2], ex[4][2];
-        bool ch_ok[2], pix_ok[4];
-        size_t opix[4];
+        bool pix_ok[4];
+        unsigned opix[4];                  // element offsets fit 32 bits (checked by the dispatcher): four registers, not eight
+#pragma unroll
+        for (int y = 0; y < 4; ++y) {
+            const int yy = oy + (y >> 1), xx = ox + (y & 1);
+            pix_ok[y] = tile_valid && b < p.B && yy < p.Ho && xx < p.Wo;
+            opix[y] = (unsigned)(((b * p.Ho + yy) * p.Wo + xx) * p.Cout);
+        }
+        float* slab = p.slabs + (size_t)grp * kWinoSlabFloats + (size_t)wave * 2048 + launder(lane) * 4;     // rows [n][2x2 output], 1 KiB each
+        const float* slab0 = p.slabs + (size_t)wave * 2048 + launder(lane) * 4;
+        if (!owner) {
+            mfma_results_settle();
+            vmem_drain_visible();          // this unit's LDS-DMA (issued long ago): no DMA wait behind finish()
+        }
+        // The two 16-channel halves of the wave's tile one after the other: with both in flight (round 5) the 128 accumulators, 32
+        // residual registers and the partial transforms did not fit 256 VGPRs, and an accumulator reloaded from scratch at the end
+        // of finish() made hipcc drain vmcnt(0) -- and the LDS-DMA in flight -- at the third MFMA position of EVERY unit.  The
+        // round trips this serialises are covered by the partner wave's MFMAs (schedule below).
+        float4 outv[4][2];
+        bool ch_ok[2];
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
             const int ch = nbase + 16 * n;
             ch_ok[n] = ch < p.Cout;
             const int nc = ch_ok[n] ? ch : 0;
-            sc[n] = (owner && p.scale) ? *reinterpret_cast<const float4*>(p.scale + nc) : make_float4(1.f, 1.f, 1.f, 1.f);
-            sh[n] = (owner && p.shift) ? *reinterpret_cast<const float4*>(p.shift + nc) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+            float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f), ex[4];
+            if (owner) {
+                if (p.scale) sc = *reinterpret_cast<const float4*>(p.scale + nc);
+                if (p.shift) sh = *reinterpret_cast<const float4*>(p.shift + nc);
+            }
 #pragma unroll
-        for (int y = 0; y < 4; ++y) {
-            const int yy = oy + (y >> 1), xx = ox + (y & 1);
-            pix_ok[y] = tile_valid && b < p.B && yy < p.Ho && xx < p.Wo;
-            opix[y] = (((size_t)b * p.Ho + yy) * p.Wo + xx) * p.Cout;
-#pragma unroll
-            for (int n = 0; n < 2; ++n)
-                ex[y][n] = (owner && has_res && ch_ok[n] && pix_ok[y]) ? *reinterpret_cast<const float4*>(p.residual + opix[y] + nbase + 16 * n)
-                                                                       : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        // Y = A^T M A, lane-local: T_0[j] = M_0j + M_1j + M_2j, T_1[j] = M_1j - M_2j - M_3j, Y[dy][0] = T0 + T1 + T2, Y[dy][1] = T1 - T2 - T3
-        f32x4 Y[4][2];
-#pragma unroll
-        for (int n = 0; n < 2; ++n) {
-            f32x4 T0[4], T1[4];
+            for (int y = 0; y < 4; ++y)
+                ex[y] = (owner && has_res && ch_ok[n] && pix_ok[y]) ? *reinterpret_cast<const float4*>(p.residual + opix[y] + ch)
+                                                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+            // Y = A^T M A, lane-local: T_0[j] = M_0j + M_1j + M_2j, T_1[j] = M_1j - M_2j - M_3j, Y[dy][0] = T0 + T1 + T2, Y[dy][1] = T1 - T2 - T3
+            f32x4 T0[4], T1[4], Y[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 T0[j] = (acc[j][n] + acc[4 + j][n]) + acc[8 + j][n];
                 T1[j] = (acc[4 + j][n] - acc[8 + j][n]) - acc[12 + j][n];
             }
-            Y[0][n] = (T0[0] + T0[1]) + T0[2]; Y[1][n] = (T0[1] - T0[2]) - T0[3];
-            Y[2][n] = (T1[0] + T1[1]) + T1[2]; Y[3][n] = (T1[1] - T1[2]) - T1[3];
-        }
-        if (CLSLAM_WINO_TRACE > 1) stamp();      // output transform done
-        if (!owner) {
-            float* slab = p.slabs + (size_t)grp * kWinoSlabFloats + (size_t)wave * 2048 + launder(lane) * 4;
-            mfma_results_settle();
-            vmem_drain_visible();          // this unit's LDS-DMA (issued long ago): no closing wait later
+            Y[0] = (T0[0] + T0[1]) + T0[2]; Y[1] = (T0[1] - T0[2]) - T0[3];
+            Y[2] = (T1[0] + T1[1]) + T1[2]; Y[3] = (T1[1] - T1[2]) - T1[3];
+            if (!owner) {
 #pragma unroll
-            for (int y = 0; y < 4; ++y)
-#pragma unroll
-                for (int n = 0; n < 2; ++n) coherent_store4(slab + (y * 2 + n) * 256, Y[y][n]);
-            publish_pending = true;        // the flag goes out behind the NEXT unit's closing wait (a full one) and barrier
-            return true;
-        }
-        if (ncon > 0) {
-            const float* slab0 = p.slabs + (size_t)wave * 2048 + launder(lane) * 4;
+                for (int y = 0; y < 4; ++y) coherent_store4(slab + (n * 4 + y) * 256, Y[y]);
+                continue;
+            }
             for (int c = 0; c < ncon; ++c) {
-                f32x4 part[8];
-                coherent_load4x8(slab0 + (size_t)(grp - 1 - c) * kWinoSlabFloats, part);
+                f32x4 part[4];
+                coherent_load4x4(slab0 + (size_t)(grp - 1 - c) * kWinoSlabFloats + n * 1024, part[0], part[1], part[2], part[3]);
 #pragma unroll
                 for (int y = 0; y < 4; ++y)
 #pragma unroll
-                    for (int n = 0; n < 2; ++n)
+                    for (int r = 0; r < 4; ++r) Y[y][r] += part[y][r] + poison;
+            }
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) Y[y][n][r] += part[y * 2 + n][r] + poison;
+            for (int y = 0; y < 4; ++y) {
+                float4 v = make_float4(Y[y][0] * sc.x + sh.x, Y[y][1] * sc.y + sh.y, Y[y][2] * sc.z + sh.z, Y[y][3] * sc.w + sh.w);
+                v.x += ex[y].x; v.y += ex[y].y; v.z += ex[y].z; v.w += ex[y].w;
+                v.x = apply_act(v.x, p.act); v.y = apply_act(v.y, p.act); v.z = apply_act(v.z, p.act); v.w = apply_act(v.w, p.act);
+                outv[y][n] = v;
             }
         }
-        if (CLSLAM_WINO_TRACE > 1) stamp();      // gathered
-        if (kWinoDbg & 1) { if (Y[0][0][0] == 12345.678f) uncounted_flag_store((unsigned*)p.out, 1u); return false; }
-#pragma unroll
-        for (int y = 0; y < 4; ++y)
-#pragma unroll
-            for (int n = 0; n < 2; ++n) {
-                float4 v = make_float4(Y[y][n][0] * sc[n].x + sh[n].x, Y[y][n][1] * sc[n].y + sh[n].y, Y[y][n][2] * sc[n].z + sh[n].z,
-                                       Y[y][n][3] * sc[n].w + sh[n].w);
-                const float4 e = ex[y][n];
-                v.x += e.x; v.y += e.y; v.z += e.z; v.w += e.w;
-                v.x = apply_act(v.x, p.act); v.y = apply_act(v.y, p.act); v.z = apply_act(v.z, p.act); v.w = apply_act(v.w, p.act);
-                ex[y][n] = v;
-            }
-        // every compiler-visible load has been consumed and this wave's LDS-DMA of the unit has landed: no closing wait for this
-        // unit, the stores stay in flight
+        if (!owner) {
+            publish_pending = true;        // (the slab stores have been acknowledged by then without a wait of their own)
+            return true;
+        }
+        if (CLSLAM_WINO_TRACE == 2) stamp();      // transformed, gathered
+        if (kWinoDbg & 1) { if (outv[0][0].x == 12345.678f) uncounted_flag_store((unsigned*)p.out, 1u); return false; }
+        // every compiler-visible load has been consumed and this wave's LDS-DMA of the unit has landed: no DMA wait behind
+        // finish(), the stores stay in flight
         vmem_drain_visible();
 #pragma unroll
         for (int y = 0; y < 4; ++y)
 #pragma unroll
             for (int n = 0; n < 2; ++n)
-                if (ch_ok[n] && pix_ok[y]) uncounted_store4(p.out + opix[y] + nbase + 16 * n, ex[y][n]);
+                if (ch_ok[n] && pix_ok[y]) uncounted_store4(p.out + opix[y] + nbase + 16 * n, outv[y][n]);
         return true;
     };
 
-    // ---- prologue.  Pipeline invariant at the barrier that opens unit k: U(k), U(k+1) and the patch of unit k have landed
-    // (U(k+2) and the patch of unit k+1 are fetched during unit k).  The input transform of a unit runs at its START, not a unit
-    // ahead: a second set of transformed operands does not fit the 256 registers of a wave beside the 128 accumulators (hipcc
-    // spilled the raw pixels straight to scratch), and with two waves per SIMD it does not have to -- while one wave reads and
-    // transforms, its partner holds the matrix pipe.
+    // ---- schedule: one workgroup barrier per unit.  Invariant at the barrier that opens unit k: U(k), U(k+1) and the patch of unit
+    // k have landed; U(k+2) and a new patch for unit k+1 are fetched during unit k.
+    // What a unit costs (round 6, per-wave s_memtime stamps, profiles/r06_wino_waves_*.txt): its 4096 matrix cycles per SIMD plus
+    // everything else its two waves issue -- the SIMD runs one wave's VALU / LDS instructions and its partner's MFMAs mostly one
+    // after the other, whatever the phase relation of the two.  Two schedules that tried to hide the input transform were built
+    // and measured on the MI355X, both lost, both are gone (profiles/r06_wino_stagger.txt):
+    //   * the two waves of a SIMD half a unit apart (two barriers per unit): the transform took 2400-3000 cycles beside the
+    //     partner's MFMAs against 1450 when both waves transform together -- the sum stayed, the second barrier cost 15-20 %;
+    //   * the raw pixels of unit k+1 read behind the positions of unit k into the operand registers they release: 32 more live
+    //     registers at the top of a unit, hipcc spilled the DMA addresses and drained vmcnt(0) between the patch pieces (-10 %).
+    // What paid (+13...20 % over round 5 on every layer and batch size) is fewer instructions beside the MFMAs and no drain of the
+    // DMA in flight: packed additions (v_pk_add_f32) in the transform, one v_xad_u32 per read address, U fragments requested two
+    // positions ahead, the DMA row decomposition hoisted out of the loop, finish() without a workgroup barrier and without a
+    // register spill (an accumulator reloaded from scratch at its end made hipcc drain vmcnt(0) at the third position of EVERY
+    // unit in round 5; the ISA of this loop has no compiler-placed vmcnt wait any more: tools/isa_scan.py wino8).
     Cur cc{t_hi, seg_lo(t_hi), seg_hi(t_hi)};       // unit k
     Cur c1 = cc;                                    // unit k + 1
     if (nunits > 1) advance(c1);
     Cur c2 = c1;                                    // unit k + 2
-    int pcur = 0, ucur = 0;                         // patch / U buffer of unit k
-    {
-        dma_setup_tile(cc.t);
+    auto new_patch = [](const Cur& a, const Cur& b) { return b.t != a.t || (b.s >> 1) != (a.s >> 1); };
+    auto issue_patch = [&](const Cur& c, int pbuf) {
+        if (c.t != dma_tile) dma_setup_tile(c.t);
 #pragma unroll
-        for (int k = 0; k < MYP; ++k) dma_patch_piece(k, cc.s >> 1, 0);
-        dma_u_group(dma_tn, cc.s, 0);
-        if (nunits > 1) {
-            int tn1, rx, ry, rb;
-            decode_tile(c1.t, tn1, rx, ry, rb);
-            dma_u_group(tn1, c1.s, 1);
-        }
-        if (nunits > 1) dma_wait_keep4(); else dma_wait_all();      // U(1), issued last, may stay in flight
+        for (int k = 0; k < MYP; ++k) dma_patch_piece(k, c.s >> 1, pbuf);
+    };
+    auto issue_u = [&](const Cur& c, int ubuf) {
+        int tn, rx, ry, rb;
+        decode_tile(c.t, tn, rx, ry, rb);
+        dma_u_group(tn, c.s, ubuf);
+    };
+    int pb = 0, ub = 0;                             // patch / U buffer of unit k
+    {
+        issue_patch(cc, 0);
+        issue_u(cc, 0);
+        if (nunits > 1) issue_u(c1, 1);
+        dma_wait_all();
         wg_barrier_keep_dma();
     }
-    stamp(); stamp();
+    stamp();
+    if (CLSLAM_WINO_TRACE && CLSLAM_WINO_TRACE < 3) stamp();
+
+    auto publish = [&]() {
+        // this wave's slab rows (stored a unit ago) have been acknowledged: its own flag
+        dma_wait_all();
+        if (lane == 0) uncounted_flag_store(&p.flags[grp * 8 + wave], p.epoch);
+        publish_armed = false;
+    };
+    // U operand fragments are requested TWO positions ahead: the faster wave of a SIMD runs a position in ~130 cycles, less than an
+    // LDS round trip beside the DMA traffic
+    constexpr int kUAfter = 4;                      // U(k+2) goes out behind this many positions
+    auto uf_load = [&](const float* Us, float2 (&uf)[3][2], int pos) __attribute__((always_inline)) {
+        uf[pos % 3][0] = *reinterpret_cast<const float2*>(&Us[pos * 512 + urow]);
+        uf[pos % 3][1] = *reinterpret_cast<const float2*>(&Us[pos * 512 + urow + 128]);
+    };
 
     for (int k = 0; k < nunits; ++k) {
         const bool has1 = k + 1 < nunits, has2 = k + 2 < nunits;
         if (has2) { c2 = c1; advance(c2); }
-        const bool need_patch = has1 && (c1.t != cc.t || (c1.s >> 1) != (cc.s >> 1));
-        if (need_patch && c1.t != dma_tile) dma_setup_tile(c1.t);
-        int tn2 = 0;
-        if (has2) { int rx, ry, rb; decode_tile(c2.t, tn2, rx, ry, rb); }
-        const float* Us = Ubuf + ucur * kWinoUFloats;
-        const int unn = ucur == 0 ? 2 : ucur - 1;
-        float2 V[16];
+        const bool np1 = has1 && new_patch(cc, c1);
+        const int ub2 = ub == 0 ? 2 : ub - 1;       // buffer of U(k + 2) = the one U(k - 1) has left
+        // the other patch buffer was last read by the transform of a unit < k: behind the barrier that opened this unit
+        if (np1) issue_patch(c1, pb ^ 1);
+        const float* Us = Ubuf + ub * kWinoUFloats;
+        f32x2 V[16];
         if (!(kWinoDbg & 16)) {
-            load_raw(Pbuf + pcur * kWinoPatchFloats, cc.s & 1, V);
+            load_raw(pb, cc.s & 1, V);
 #pragma unroll
             for (int hs = 0; hs < 16; ++hs) transform_half(V, hs);
         } else {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) V[i] = make_float2(1.f, 1.f);
+            for (int i = 0; i < 16; ++i) V[i] = f32x2{1.f, 1.f};
         }
-        float2 uf[2][2];
-        uf[0][0] = *reinterpret_cast<const float2*>(&Us[urow]);
-        uf[0][1] = *reinterpret_cast<const float2*>(&Us[urow + 128]);
+        if (CLSLAM_WINO_TRACE >= 3) { asm volatile("" : "+v"(V[0]), "+v"(V[15])); stamp(); }
+        float2 uf[3][2];
+        uf_load(Us, uf, 0);
+        uf_load(Us, uf, 1);
 #pragma unroll
         for (int pos = 0; pos < 16; ++pos) {
-            if (pos < 15) {
-                uf[(pos + 1) & 1][0] = *reinterpret_cast<const float2*>(&Us[(pos + 1) * 512 + urow]);
-                uf[(pos + 1) & 1][1] = *reinterpret_cast<const float2*>(&Us[(pos + 1) * 512 + urow + 128]);
-            }
+            if (pos + 2 < 16) uf_load(Us, uf, pos + 2);
             if (!(kWinoDbg & 4)) {
-                const float2 a0 = uf[pos & 1][0], a1 = uf[pos & 1][1], bq = V[pos];
-                acc[pos][0] = mfma_16x16x4(a0.x, bq.x, acc[pos][0]);
-                acc[pos][1] = mfma_16x16x4(a1.x, bq.x, acc[pos][1]);
-                acc[pos][0] = mfma_16x16x4(a0.y, bq.y, acc[pos][0]);
-                acc[pos][1] = mfma_16x16x4(a1.y, bq.y, acc[pos][1]);
+                const float2 a0 = uf[pos % 3][0], a1 = uf[pos % 3][1];
+                const f32x2 bq = V[pos];
+                acc[pos][0] = mfma_16x16x4(a0.x, bq[0], acc[pos][0]);
+                acc[pos][1] = mfma_16x16x4(a1.x, bq[0], acc[pos][1]);
+                acc[pos][0] = mfma_16x16x4(a0.y, bq[1], acc[pos][0]);
+                acc[pos][1] = mfma_16x16x4(a1.y, bq[1], acc[pos][1]);
             }
-            if (pos < MYP) { if (need_patch) dma_patch_piece(pos, c1.s >> 1, pcur ^ 1); }
-            if (pos == 4) { if (has2) dma_u_group(tn2, c2.s, unn); }
+            if (pos == kUAfter - 1 && has2) issue_u(c2, ub2);
             sched_fence();
         }
-        pcur ^= need_patch ? 1 : 0;
-        ucur = ucur == 2 ? 0 : ucur + 1;
-        stamp();
-        const bool publish_now = publish_pending;
-        int closing = (k + 2 >= nunits) ? 0 : 1;
+        if (CLSLAM_WINO_TRACE) stamp();
+        bool drained = false;
         if (cc.s + 1 >= cc.hi) {
-            closing = finish(cc.t, seg_lo(cc.t), cc.hi) ? 2 : 0;
+            drained = finish(cc.t, seg_lo(cc.t), cc.hi);
             if (has1) zero_acc();
+            // (free here -- finish() has just drained -- and it leaves hipcc's wait-count pass with nothing pending on ANY path
+            // out of finish(): otherwise it drains vmcnt(0), i.e. the DMA just issued, at the first LDS read of the next unit)
+            vmem_drain_visible();
         }
-        stamp();
-        cc = c1; c1 = c2;
-        if (publish_now) closing = 0;
-        if (closing == 0) dma_wait_all(); else if (closing == 1) dma_wait_keep4();
+        if (CLSLAM_WINO_TRACE) stamp();
+        // every wave's DMA pieces of U(k+1) and of the patch of unit k+1 have landed behind this wait and the barrier; the four
+        // pieces of U(k+2), the youngest group, stay in flight
+        if (publish_armed) publish();
+        else if (!drained) { if (has2) dma_wait_keep4(); else dma_wait_all(); }
+        publish_armed = publish_pending; publish_pending = false;
+        if (CLSLAM_WINO_TRACE >= 3) stamp();
         wg_barrier_keep_dma();
-        if (publish_now) {
-            if (tid == 0) uncounted_flag_store(&p.flags[grp], p.epoch);
-            publish_pending = false;
-        }
-        stamp();
+        if (CLSLAM_WINO_TRACE) stamp();
+        pb ^= np1 ? 1 : 0;
+        ub = ub == 2 ? 0 : ub + 1;
+        cc = c1; c1 = c2;
     }
-    if (publish_pending) {
-        stores_complete();
-        __syncthreads();
-        if (tid == 0) uncounted_flag_store(&p.flags[grp], p.epoch);
-    }
+    if (publish_armed || publish_pending) publish();
 }
 
 // ---- U = G g G^T, written as the LDS image of the kernel's stages --------------------------------------------------------
@@ -496,15 +546,11 @@ int conv3x3_wino_supported(const clslam_conv_desc* d) {
 // Workgroups of a launch: one per CU the descriptor grants it (clslam_conv_desc.cu_limit; CLSLAM_WINO_GROUPS / CLSLAM_SK_GROUPS
 // override it for experiments).
 static int wino_groups(const clslam_conv_desc* d) {
-    static const int forced = [] {
-        int v = 0;
-        if (const char* e = getenv("CLSLAM_SK_GROUPS")) v = std::max(1, atoi(e));
-        if (const char* e = getenv("CLSLAM_WINO_GROUPS")) v = std::max(1, atoi(e));
-        return v;
-    }();
     int g = sk_device_cus();
     if (d->cu_limit > 0) g = std::min(g, d->cu_limit);
-    if (forced) g = forced;
+    // experiment / test knobs, read per launch like conv_sk.hip's (tests cut the unit stream differently from case to case)
+    if (const char* e = getenv("CLSLAM_SK_GROUPS")) g = std::max(1, atoi(e));
+    if (const char* e = getenv("CLSLAM_WINO_GROUPS")) g = std::max(1, atoi(e));
     return std::min(g, kWinoMaxGroups);
 }
 
@@ -522,6 +568,10 @@ int conv3x3_wino_dispatch(const clslam_conv_desc* d, hipStream_t stream) {
         set_error("conv2d: the Winograd kernel needs a 3x3 stride-1 zero-padded conv of one source with weight_wino set");
         return CLSLAM_ERR_INVALID;
     }
+    if ((long long)d->batch * d->out_h * d->out_w * d->ch_out >= (1ll << 31) || (long long)d->batch * d->in_h * d->in_w * d->ch_a >= (1ll << 31)) {
+        set_error("conv2d: the Winograd kernel indexes its tensors with 32-bit element offsets");
+        return CLSLAM_ERR_INVALID;
+    }
     WinoK k;
     k.src = d->src_a; k.u = d->weight_wino; k.scale = d->scale; k.shift = d->shift; k.residual = d->residual; k.out = d->out;
     k.B = d->batch; k.Hi = d->in_h; k.Wi = d->in_w; k.Cin = d->ch_a; k.Ho = d->out_h; k.Wo = d->out_w; k.Cout = d->ch_out;
@@ -536,7 +586,7 @@ int conv3x3_wino_dispatch(const clslam_conv_desc* d, hipStream_t stream) {
     if (const char* e = getenv("CLSLAM_SK_B_FASTEST")) k.b_fastest = atoi(e);
     const int G = (int)std::min<long long>(wino_groups(d), k.units);
     k.G = G;
-    const size_t need = (size_t)kWinoSlabOffsetBytes + (size_t)G * kWinoSlabFloats * sizeof(float) + (CLSLAM_WINO_TRACE ? (size_t)G * 64 * 8 : 0);
+    const size_t need = (size_t)kWinoSlabOffsetBytes + (size_t)G * kWinoSlabFloats * sizeof(float) + (CLSLAM_WINO_TRACE ? (size_t)G * 64 * 8 * (CLSLAM_WINO_TRACE >= 3 ? 8 : 1) : 0);
     if (!d->workspace || d->workspace_bytes < need) {
         set_error("conv2d: the Winograd kernel needs a zero-filled workspace of %zu bytes on the launching stream", need);
         return CLSLAM_ERR_INVALID;

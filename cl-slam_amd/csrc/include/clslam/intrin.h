@@ -113,6 +113,13 @@ __device__ __forceinline__ void lds_dma16(const float* gsrc, float* lds_wave_bas
 __device__ __forceinline__ unsigned lds_addr(const float* lds_ptr) {
     return __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) const float*)lds_ptr);
 }
+// a wave-uniform value made opaque in a scalar register
+__device__ __forceinline__ void launder_uniform(unsigned& v) { v = __builtin_amdgcn_readfirstlane(v); asm volatile("" : "+s"(v)); }
+// 8-byte LDS read at lds_addr(array) + a BYTE offset the kernel computed itself (one v_xad_u32 for swizzle + buffer base; through
+// a generic float* index hipcc forms the address with a shift-add per read)
+__device__ __forceinline__ f32x2 lds_read_f32x2(const float*, unsigned lds_base_addr, unsigned byte_offset) {
+    return *(const __attribute__((address_space(3))) f32x2*)(size_t)(lds_base_addr + byte_offset);
+}
 __device__ __forceinline__ void lds_dma16_at(const float* gsrc, float*, unsigned lds_base_addr, unsigned float_offset) {
     unsigned keep;
     const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base_addr + float_offset * 4u);     // (uniform; not always provably so)

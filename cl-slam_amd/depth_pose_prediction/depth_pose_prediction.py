@@ -484,8 +484,10 @@ class DepthPosePrediction:
             ext = torch.cat([torch.zeros(18, device=self.device), self._dp_tag(0)])
             dist.all_reduce(ext, group=group)
             losses = ext[:18]
-            self._check_dp_tag(ext[18:22].cpu())
             self._losses_dev = losses
+            # Same order as a rank WITH samples (and as _dp_abort_step): the step's gradient collective(s) and the guarded
+            # optimizer launch go out FIRST, the status word is looked at afterwards -- a rank that raised right behind the loss
+            # exchange would leave its peers' gradient all-reduce unmatched (they post it before they check, _staged_losses).
             eng._g.zero_()
             if bucketed:
                 for _name, lo, hi in eng.bucket_ranges():
@@ -495,7 +497,13 @@ class DepthPosePrediction:
             self.optimizer.loss_guard = losses[17:18]
             self.optimizer.step()
             self.optimizer.loss_guard = None
-            self._raise_on_nan(eng.losses_dict(losses.detach().cpu()), undo_step=True)
+            host = ext.detach().cpu()
+            try:
+                self._check_dp_tag(host[18:22])
+            except DataParallelPeerFailure:
+                eng.adam_step_count -= 1     # the guarded launch saw the peer's NaN: nothing was applied
+                raise
+            self._raise_on_nan(eng.losses_dict(host[:18]), undo_step=True)
         H, W, dev = self.height, self.width, self.device
         E = lambda *shape: torch.empty(*shape, device=dev)  # noqa: E731
         outputs: Dict[Any, Tensor] = {}
@@ -696,7 +704,13 @@ class DepthPosePrediction:
                 inputs[k] = inputs[k].to(dev)
             return None
         if self._copy_stream is None:
-            self._copy_stream = torch.cuda.Stream(device=dev)
+            # HIGH priority, and not for its urgency: HIP multiplexes a process's streams onto a handful of hardware queues
+            # (four per priority level), in-order each.  As the sixth normal-priority stream of the process the copy stream
+            # landed on the POSE branch's hardware queue: the pose encoder's first kernel queued behind the barrier packets of
+            # the whole upload, the upload of the unread entries queued behind the whole pose encoder, and the backward behind
+            # that (profiles/r06_timeline_e2e_before.txt: 1.4 ms of the 4.25 ms end-to-end frame).  Queues are pooled per
+            # priority, so a high-priority stream shares its queue with none of the engine's compute streams.
+            self._copy_stream = torch.cuda.Stream(device=dev, priority=int(os.environ.get('CLSLAM_PRIO_COPY', '-1')))
         cur = torch.cuda.current_stream(dev)
         cs = self._copy_stream
         # No cs.wait_stream(cur): the device blocks are allocated under the copy stream (its own pool in torch's caching
@@ -730,13 +744,13 @@ class DepthPosePrediction:
         if not extra:
             return
         dev = self.device
-        cur = torch.cuda.current_stream(dev)
+        # the CALLER's stream -- during a detached training call torch's current stream is the engine's own, and a wait there
+        # would put the rest of the step (view synthesis, loss, the whole backward) behind 22 copies it never reads
+        cur = self.engine._caller if self.engine._caller is not None else torch.cuda.current_stream(dev)
         with torch.cuda.stream(self._copy_stream):
             for k in extra:
                 t = inputs[k].to(dev, non_blocking=True)
                 t.record_stream(cur)         # never read by the engine: only the caller's stream may touch it
-                if self.engine._caller is not None:
-                    t.record_stream(self.engine._caller)
                 inputs[k] = t
             ev = torch.cuda.Event()
             ev.record(self._copy_stream)

@@ -366,7 +366,8 @@ int clslam_conv_profile_end(float* ms, int capacity, int* count);
  *   clslam_handoff_wait(ev, producer, consumer):  `consumer` stream waits for `ev`; if no launch has taken the armed
  *                             event since clslam_handoff_arm (an op that does not support it, an empty batch) it is
  *                             recorded on `producer` first -- never a missing dependency.
- * Events come from clslam_handoff_event_create (timing disabled) and may be re-armed once waited on.                 */
+ * Events come from clslam_handoff_event_create (timing disabled) and may be re-armed once waited on.  Arming while another
+ * event is still armed (its launch failed before it went out) replaces that event: the stale one was never recorded.     */
 void* clslam_handoff_event_create(void);
 void clslam_handoff_event_destroy(void* event);
 int clslam_handoff_arm(void* event);

@@ -86,6 +86,8 @@ inline void spin_pause() { ::emu_yield_os(); }   // the producer block runs on a
 // LDS-DMA emulated as an immediate copy: lane l's 16 bytes land at lds_wave_base + l * 16
 inline void lds_dma16(const float* gsrc, float* lds_wave_base) { memcpy(lds_wave_base + lane_id() * 4, gsrc, 16); }
 inline unsigned lds_addr(const float*) { return 0u; }
+inline void launder_uniform(unsigned&) {}
+inline f32x2 lds_read_f32x2(const float* lds_array, unsigned, unsigned byte_offset) { f32x2 v; memcpy(&v, (const char*)lds_array + byte_offset, 8); return v; }
 inline void lds_dma16_at(const float* gsrc, float* lds_array, unsigned, unsigned float_offset) { memcpy(lds_array + float_offset + lane_id() * 4, gsrc, 16); }
 inline void lds_dma16_x4(const float* gsrc, float* lds_array, unsigned, unsigned float_offset) { for (int i = 0; i < 4; ++i) memcpy(lds_array + float_offset + i * 256 + lane_id() * 4, gsrc + i * 256, 16); }
 inline void dma_wait_all() {}

@@ -65,7 +65,23 @@ def test_binding_checks_the_abi_version():
     old = _lib.ABI_VERSION
     try:
         _lib.ABI_VERSION = old + 1
+        # ... and a stale library also lacks the entry points added since: the version is compared BEFORE they are resolved
+        _lib._SIGNATURES['clslam_entry_point_of_a_later_abi'] = []
         with pytest.raises(_lib.ClslamError, match='ABI version'):
             _lib.Library(_lib.LIB_PATH, require_device=True)
     finally:
         _lib.ABI_VERSION = old
+        _lib._SIGNATURES.pop('clslam_entry_point_of_a_later_abi', None)
+
+
+def test_a_stale_armed_handoff_event_does_not_block_the_next_arm():
+    """ADVICE r5: a launch that fails its argument checks between clslam_handoff_arm and clslam_handoff_wait leaves the event armed;
+    the next arm used to fail forever ('an armed event has not been waited on').  Now it replaces the stale event.  (Pointer
+    bookkeeping only -- nothing is launched, the fake handles are never dereferenced.)"""
+    from clslam_hip import _lib
+    lib = _lib.Library(_lib.LIB_PATH, require_device=True)
+    lib.call('clslam_handoff_arm', ctypes.c_void_p(0x1000))
+    lib.call('clslam_handoff_arm', ctypes.c_void_p(0x2000))      # raised ClslamError before
+    import pytest
+    with pytest.raises(_lib.ClslamError, match='null event'):
+        lib.call('clslam_handoff_arm', None)

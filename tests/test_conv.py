@@ -252,7 +252,8 @@ WINO_CASES = [
 @pytest.mark.parametrize('case', WINO_CASES)
 def test_conv2d_winograd(backend, case, config, monkeypatch):
     """conv_wino.hip (config 40): F(2x2,3x3) on the 16x16x4 MFMA with the input transform in registers.  Same result as torch
-    for every cut of the unit stream, bitwise repeatable, hand-off flags back at zero; fp32 Winograd carries about twice the
+    for every cut of the unit stream, bitwise repeatable on the same scratch (the per-wave hand-off flags hold the launch's epoch and
+    are never reset: a second launch must not take the first one's flags for its own); fp32 Winograd carries about twice the
     rounding error of the direct form (3.6e-7...6.9e-7 of max|y| at 64...512 channels), far inside the 2e-5 of this file."""
     dev = use_backend(backend)
     B, H, W, Cin, Cout, pad, act, resid, groups = case
@@ -277,7 +278,6 @@ def test_conv2d_winograd(backend, case, config, monkeypatch):
     assert rel_err(outs[0], ref) < 2e-5, rel_err(outs[0], ref)
     assert torch.equal(outs[0], outs[1])
     assert rel_err(outs[0], outs[2]) < 1e-5
-    assert int(ws[:65536].view(torch.int32).abs().sum()) == 0
     with pytest.raises(Exception, match='weight_wino'):
         ops.conv2d(t(x), t(w), out, ksize=3, pad=pad, config=config, workspace=ws)
 

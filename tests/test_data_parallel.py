@@ -252,3 +252,53 @@ def test_a_failed_rank_is_agreed_on_by_every_rank(tmp_path):
     assert r0['same'] and r1['same']
     assert r0['waited'] < 60 and r1['waited'] < 60
     assert torch.equal(r0['w'], r1['w'])
+
+
+def _peer_failure_with_empty_shard_worker(rank, world, port, out_dir):
+    for p in (ROOT / 'cl-slam_amd', ROOT, ROOT / 'tests'):
+        sys.path.insert(0, str(p))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), CLSLAM_EMU_THREADS='4')
+    torch.set_num_threads(2)
+    import time
+    import torch.distributed as dist
+    from clslam_hip import synth
+    from emu_util import use_backend
+    from predictor_util import make_predictor
+    use_backend('emu')
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    p = make_predictor(H, W, 1)
+    n = 1 if rank < 2 else 0                        # shards 1 + 1 + 0: the third rank holds no sample (world > minibatch)
+    p.enable_data_parallel(2, min(rank, 2))
+    full = synth.make_batch(2, H, W, seed=4)
+    batch = {k: v[rank:rank + n].clone() for k, v in full.items()}
+    p.adapt(None, dict(batch))                      # a good step first
+    w1, steps1 = p.engine.w.clone(), p.engine.adam_step_count
+    bad = dict(batch)
+    if rank == 1:
+        del bad['rgb_aug', -1, 0]
+    t0 = time.monotonic()
+    kind, agreed = '', False
+    try:
+        p.adapt(None, bad)
+    except Exception as e:          # noqa: BLE001
+        kind, agreed = type(e).__name__, bool(getattr(e, 'dp_agreed', False))
+    waited = time.monotonic() - t0
+    same = bool(torch.equal(p.engine.w, w1)) and p.engine.adam_step_count == steps1
+    p.adapt(None, dict(batch))                      # every collective of the failed step was matched: the next one pairs up
+    torch.save({'kind': kind, 'agreed': agreed, 'waited': waited, 'same': same, 'w': p.engine.w.clone()}, Path(out_dir) / f'peer3_{rank}.pt')
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_a_failed_rank_beside_an_empty_shard_leaves_no_collective_unmatched(tmp_path):
+    """the rank WITHOUT samples used to raise right behind the loss exchange, before posting the step's gradient
+    all-reduce(s) -- the ranks with samples (and the failing rank's _dp_abort_step) post them first and check afterwards, so one
+    collective stayed unmatched until the communicator timed out.  Three ranks (1 + 1 + 0 samples), the middle one fails: all
+    three raise at once, nobody applies the step, and the following good step runs on all of them."""
+    port = 29500 + (os.getpid() % 2000) + 41
+    mp.spawn(_peer_failure_with_empty_shard_worker, args=(3, port, str(tmp_path)), nprocs=3, join=True)
+    r = [torch.load(tmp_path / f'peer3_{i}.pt') for i in range(3)]
+    assert r[0]['kind'] == 'DataParallelPeerFailure' and r[2]['kind'] == 'DataParallelPeerFailure'
+    assert r[1]['kind'] == 'KeyError' and r[1]['agreed']
+    assert all(x['same'] for x in r) and all(x['waited'] < 60 for x in r)
+    assert torch.equal(r[0]['w'], r[1]['w']) and torch.equal(r[0]['w'], r[2]['w'])
