@@ -204,6 +204,9 @@ class Engine:
         # (three all-reduces, same slices, same order) is the same on every rank whatever its workspace / overlap state.
         self.grad_buckets = int(os.environ.get('CLSLAM_GRAD_BUCKETS', '3'))
         self.grads_synced = False
+        self.time_exchange = False    # bench.py --gpus N: time the bucket all-reduces (exchange_report())
+        self.exchange_events: List[Any] = []
+        self.exchange_main_done = None
         self.tail_stream = pool.get('tail')
         self._tail_event = None       # optimizer step in flight on tail_stream
         self._tail_open = False       # backward() left its reduction on tail_stream; adam() closes it
@@ -231,7 +234,7 @@ class Engine:
         # +4 % (one triplet does not fill the chip: latency counts, not occupancy) and 33 triplets +3.7 % (every launch is long
         # enough to fill it alone) -- hence the band.  CLSLAM_CU_LIMIT=<n> forces a value (0: the whole chip).
         self.cu_limit_env = os.environ.get('CLSLAM_CU_LIMIT')
-        self._cu_enc = self._cu_dec = 0     # set per forward(); the stand-alone callables (run_encoder, ...) take the whole chip
+        self._cu_enc = self._cu_dec = self._cu_pose = self._cu_depth = 0     # set per forward(); the stand-alone callables (run_encoder, ...) take the whole chip
         # OPT-IN experiment (CLSLAM_EARLY_LOSS=1), steps 2..S of adapt(steps=S) (decoders only): the view synthesis, photometric
         # stage and loss backward of the COARSE scales 3, 2, 1 issued on the leaf stream as soon as their disparity head has run,
         # beside the decoder levels that follow; only scale 0's remain between the decoder and the data-gradient chain.  The
@@ -284,7 +287,7 @@ class Engine:
                 and ops.PROFILE is None)
 
     def cu_limit(self, B: int, phase: str = 'encoders') -> int:
-        """phase: 'encoders' (the two frozen encoders side by side: half of the chip each), 'decoders', 'backward' (the whole
+        """phase: 'enc_pose' / 'enc_depth' (the two frozen encoders side by side: 5/8 and 3/8 of the chip), 'decoders', 'backward' (the whole
         chip: in steps 2..S of adapt(steps=S) nothing runs beside the depth decoder's launches -- and the decoders' summation
         order must not depend on whether the encoders ran, tests/test_frozen_reuse.py holds the reuse bitwise invisible)"""
         env = os.environ.get('CLSLAM_CU_LIMIT_' + phase.upper())       # experiments
@@ -292,9 +295,18 @@ class Engine:
             return int(env)
         if self.cu_limit_env is not None:
             return int(self.cu_limit_env)
-        if phase != 'encoders':
+        if not phase.startswith('enc'):
             return 0
-        return self.device_cus // 2 if (self.use_side_stream and 2 <= B <= 16) else 0
+        if not (self.use_side_stream and 2 <= B <= 16):
+            return 0
+        # The pose encoder sees 2B images, the depth encoder B (and the depth decoder follows it on the same stream): 5/8 : 3/8 of
+        # the chip instead of half each.  Measured at K = 4 (round 6, MI355X): pose / depth = 128/128 2.904, 144/112 2.871,
+        # 160/96 2.863, 176/80 2.909, 192/64 3.002, 112/144 3.007 ms per step; whole chip each 3.027.
+        if phase == 'enc_pose':
+            return self.device_cus * 5 // 8
+        if phase == 'enc_depth':
+            return self.device_cus * 3 // 8
+        return self.device_cus // 2
 
     def wait_training(self, stream=None) -> None:
         """Make `stream` (default: the current one) wait for the training step in flight: the optimizer step on the tail
@@ -548,14 +560,14 @@ class Engine:
             self._conv_ws[handle] = torch.zeros(self.CONV_WS_BYTES, dtype=torch.uint8, device=self.device)
             ops.set_conv_workspace(handle, self._conv_ws[handle])
 
-    def _encoder(self, e, bufs, n: int, stem_inputs, waits=None, stream=None, aux=None) -> List[torch.Tensor]:
+    def _encoder(self, e, bufs, n: int, stem_inputs, waits=None, stream=None, aux=None, cu_limit=None) -> List[torch.Tensor]:
         """stem_inputs: list of (img_a, img_b|None, batch offset, count); returns the 5 NHWC features.
         waits: one event per stem launch (its input image still crossing PCIe) for the current stream to wait on.
         aux: a second stream for the three 1x1 stride-2 `downsample` convolutions of the stage entries.  They read the same
         input as the stage's first 3x3 convolution and nothing depends on them until its second one, but at 0.16-0.3 GF
         they are pure launch latency (~11 us each for ~1 us of MFMA work): on `aux` they run underneath conv1 instead of
         between conv1 and conv2 of the chain.  `stream`: the stream this encoder's launches go to (needed with aux)."""
-        ops.PERSISTENT_CU_LIMIT = self._cu_enc
+        ops.PERSISTENT_CU_LIMIT = self._cu_enc if cu_limit is None else cu_limit
         ek = (id(self), 'enc', id(e), id(bufs), n)       # descriptor-cache key prefix of this encoder on these buffers
         for i, (img_a, img_b, off, cnt) in enumerate(stem_inputs):
             if waits is not None:
@@ -689,6 +701,7 @@ class Engine:
         rgb = {f: self._img(inputs['rgb', f, 0]) for f in (-1, 0, 1)}
         B = aug[0].shape[0]
         self._cu_enc, self._cu_dec = self.cu_limit(B, 'encoders'), self.cu_limit(B, 'decoders')
+        self._cu_pose, self._cu_depth = self.cu_limit(B, 'enc_pose'), self.cu_limit(B, 'enc_depth')
         ops.PERSISTENT_CU_LIMIT = self._cu_dec
         # the kernels index with the engine's resolution: refuse anything else up front
         for name, group in (('rgb_aug', aug), ('rgb', rgb)):
@@ -783,7 +796,7 @@ class Engine:
                     pf4 = ws.pf4 if reuse else self._encoder(self.enc['pose_encoder'], ws.penc, 2 * B,
                                                              [(aug[-1], aug[0], 0, B), (aug[0], aug[1], B, B)],
                                                              waits=None if inputs_ready is None else inputs_ready[1:3],
-                                                             stream=side, aux=ds_aux)[4]
+                                                             stream=side, aux=ds_aux, cu_limit=self._cu_pose)[4]
                     self.wait_training(side)      # the (frozen) encoder above does not need the optimizer step in flight
                     self._pose_decoder(ws, pf4)
                     return pf4
@@ -793,7 +806,8 @@ class Engine:
                     return ws.dfeats
                 if memo_feats is not None:
                     return memo_feats
-                return self._encoder(self.enc['depth_encoder'], ws.denc, B, [(aug[0], None, 0, B)], stream=main, aux=ds_aux)
+                return self._encoder(self.enc['depth_encoder'], ws.denc, B, [(aug[0], None, 0, B)], stream=main, aux=ds_aux,
+                                     cu_limit=self._cu_depth)
             # the host enqueues ~50 launches per branch (~0.7 ms): the depth branch is the longer
             # dependency chain (encoder + decoder), so its kernels go out first
             early = (reuse and train and self.early_loss and B * H * W <= self.early_loss_max_pixels and wg is not None
@@ -1034,6 +1048,21 @@ class Engine:
             return [('early', a_end, self.layout.size), ('deep', 0, a_end)]
         return [('all', 0, self.layout.size)]
 
+    def exchange_report(self) -> Optional[Dict[str, Any]]:
+        """After a synchronised data-parallel step with `time_exchange` set: per bucket the all-reduce's time on the tail stream
+        (events around the collective: its kernels AND whatever they waited for on that stream's queue), the part of the exchange
+        that was still running when the backward's own last kernel had finished (`exposed_ms`: what the optimizer step waits
+        for) and the fraction hidden under the backward."""
+        if not self.exchange_events or self.exchange_main_done is None:
+            return None
+        buckets = [{'bucket': n, 'mbytes': round(nb / 1e6, 2), 'ms': round(e0.elapsed_time(e1), 4)} for n, e0, e1, nb in self.exchange_events]
+        total = sum(b['ms'] for b in buckets)
+        exposed = max(0.0, self.exchange_main_done.elapsed_time(self.exchange_events[-1][2]))
+        rep = {'buckets': buckets, 'allreduce_ms': round(total, 4), 'exposed_ms': round(exposed, 4),
+               'overlap_fraction': round(1.0 - min(exposed, total) / total, 4) if total > 0 else None}
+        self.exchange_events, self.exchange_main_done = [], None
+        return rep
+
     def _bucket_sync(self, t, name: str, events, allreduce) -> None:
         """tail stream: wait for the bucket's producers, reduce its partials into the arena, all-reduce its slice."""
         tail = self.tail_stream
@@ -1042,7 +1071,16 @@ class Engine:
         table, n, lo, hi = t.bucket_tables[name]
         with torch.cuda.stream(tail):
             ops.reduce_multi(table, n, self._g)
-            allreduce(self._g[lo:hi])
+            if self.time_exchange:
+                # diagnosis of a multi-GPU run (bench.py --gpus N): how long each bucket's all-reduce took on the tail stream
+                # and how much of it was still running when the backward's own last kernel had finished
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(tail)
+                allreduce(self._g[lo:hi])
+                e1.record(tail)
+                self.exchange_events.append((name, e0, e1, (hi - lo) * 4))
+            else:
+                allreduce(self._g[lo:hi])
 
     def backward(self, B: int, defer_reduce: bool = False, allreduce=None) -> None:
         """dL/d(trainable arena) for the last training forward; fills self._g (dpp.py:312).
@@ -1129,6 +1167,9 @@ class Engine:
             if overlap:
                 # the earlier buckets went out during the backward; the last one (level 4) is complete on the main stream now
                 name, lo, hi = ranges[-1]
+                if self.time_exchange:
+                    self.exchange_main_done = torch.cuda.Event(enable_timing=True)
+                    self.exchange_main_done.record(self._main)
                 self.tail_stream.wait_stream(self._main)
                 self._bucket_sync(t, name, [], allreduce)
                 self._tail_open = True

@@ -155,48 +155,118 @@ def draw_color_jitter(brightness=(0.8, 1.2), contrast=(0.8, 1.2), saturation=(0.
 class ReplaySampleBuilder:
     """What ``ReplayBuffer._get`` (slam/replay_buffer.py:263-291) builds per replayed sample -- PNG -> RGB, the LANCZOS pyramid level
     from level, ToTensor, one drawn colour jitter on every level -- with the pixels on the GPU: the host decodes the PNGs
-    (Pillow), the raw uint8 frames cross PCIe ONCE, pyramid and jitter are three kernels per level for all samples and frames.
+    (Pillow, on a small thread pool: its decoder releases the GIL), the raw uint8 frames cross PCIe ONCE, pyramid and jitter are
+    three kernels per level for all samples and frames of a minibatch.
 
         build = ReplaySampleBuilder(height, width, scales, frames, device)
-        replay_buffer._get = build.get_one            # drop-in: same signature, same dict, image tensors on the GPU
-        samples = build.get_many(filenames)           # or: the K samples of a frame in one go (what `get` concatenates)
+        build.install(slam.replay_buffer, slam)       # the reference's Slam / ReplayBuffer objects, everything else unchanged
+        samples = build.get_many(filenames)           # or by hand: the K samples of a frame in one go
 
     Non-image entries of the pickled sample (camera matrices, relative distances, index ...) are passed through unchanged.
     """
 
     def __init__(self, height: int, width: int, scales: Sequence[int] = (0, 1, 2, 3), frames: Sequence[int] = (0, -1, 1),
-                 device=None, do_augmentation: bool = True, cache_frames: int = 0) -> None:
+                 device=None, do_augmentation: bool = True, cache_frames: int = 0, cache_bytes: int = 256 << 20,
+                 decode_threads: int = 8) -> None:
         self.height, self.width, self.scales, self.frames = int(height), int(width), tuple(scales), tuple(frames)
         self.device = torch.device('cuda' if device is None else device)
         self.do_augmentation = bool(do_augmentation)
         self.pyramid = ImagePyramid(height, width, tuple(range(max(self.scales) + 1)))
         # opt-in: keep the DECODED uint8 frames of the last `cache_frames` image files on the host (a replay buffer re-serves
-        # the same few hundred samples: a 1241x376 PNG costs ~7 ms to decode, its 1.4 MB cost nothing to keep)
+        # the same few hundred samples: a 1241x376 PNG costs ~7 ms to decode, its 1.4 MB cost nothing to keep).  Bounded by
+        # count AND by bytes (`cache_bytes`, page-locked memory on a GPU build): the oldest entries go first.
         self.cache_frames = int(cache_frames)
+        self.cache_bytes = int(cache_bytes)
+        self._cached_bytes = 0
         self._decoded: Dict = {}
+        # The K x 3 PNGs of a minibatch are decoded concurrently: Image.open(...).convert('RGB') (replay_buffer.py:271) spends its
+        # time in Pillow's C decoder with the GIL released.  0 / 1: in the calling thread, like the reference.
+        self.decode_threads = int(decode_threads)
+        self._pool = None
 
-    def _decode(self, path):
+    # ------------------------------------------------------------------------------------------------------------------
+    def install(self, replay_buffer, slam=None) -> 'ReplaySampleBuilder':
+        """Switch the REFERENCE's objects to this builder -- instance attributes only, their classes stay untouched:
+
+        * ``replay_buffer.get`` still runs the reference's own sampling code (slam/replay_buffer.py:186-227: the choice of the
+          files is its business), but with ``_get`` recording the file names instead of decoding them one by one; the K samples
+          are then built by ONE get_many() -- one upload, one pyramid / jitter pass -- and concatenated per key exactly like
+          replay_buffer.py:229-233.  The colour-jitter draws come from Python's ``random`` in the reference's order (one draw
+          per file, the sampler draws from its own numpy generator before any of them), so a seeded run consumes the same
+          random streams.
+        * ``replay_buffer._get`` (direct callers) becomes get_one.
+        * ``slam._cat_dict`` (slam/slam.py:300-309 joins the online sample, host tensors, with the replay minibatch) becomes
+          cat_dict below: torch.cat refuses mixed devices, the online entries are uploaded first.
+        """
+        builder = self
+        reference_get = replay_buffer.get
+        replay_buffer._get = self.get_one
+
+        def get(*args, **kwargs):
+            names = []
+
+            def record(filename, include_batch=True):
+                names.append((filename, include_batch))
+                return {}                                 # nothing to concatenate: replay_buffer.py:229-233 loops over its keys
+            replay_buffer._get = record
+            try:
+                stub = reference_get(*args, **kwargs)
+            finally:
+                replay_buffer._get = builder.get_one
+            if not names:
+                return stub
+            datas = builder.get_many([n for n, _ in names], include_batch=names[0][1])
+            out = datas[0]
+            for data in datas[1:]:
+                for key in out:
+                    out[key] = torch.cat([out[key], data[key]])
+            return out
+        replay_buffer.get = get
+        if slam is not None:
+            slam._cat_dict = cat_dict
+        return self
+
+    def _decode_file(self, path):
         import numpy as np
         from PIL import Image
-        key = str(path)
-        hit = self._decoded.get(key)
-        if hit is not None:
-            return hit
-        img = torch.from_numpy(np.asarray(Image.open(path).convert('RGB')).copy())      # replay_buffer.py:271
-        if self.device.type == 'cuda' and self.cache_frames > 0:
+        return torch.from_numpy(np.asarray(Image.open(path).convert('RGB')).copy())       # replay_buffer.py:271
+
+    def _keep(self, key, img):
+        if self.cache_frames <= 0:
+            return img
+        if self.device.type == 'cuda':
             img = img.pin_memory()                                  # page-locked ONCE (~40 ms): later uploads are asynchronous DMAs
-        if self.cache_frames > 0:
-            if len(self._decoded) >= self.cache_frames:
-                self._decoded.pop(next(iter(self._decoded)))
+        nbytes = img.numel()
+        while self._decoded and (len(self._decoded) >= self.cache_frames or self._cached_bytes + nbytes > self.cache_bytes):
+            old = self._decoded.pop(next(iter(self._decoded)))
+            self._cached_bytes -= old.numel()
+        if nbytes <= self.cache_bytes:
             self._decoded[key] = img
+            self._cached_bytes += nbytes
         return img
+
+    def _decode_all(self, paths):
+        """decoded uint8 frames of `paths` (cache hits first, the misses concurrently)"""
+        keys = [str(p) for p in paths]
+        out = {k: self._decoded[k] for k in keys if k in self._decoded}
+        misses = [k for k in dict.fromkeys(keys) if k not in out]
+        if len(misses) > 1 and self.decode_threads > 1:
+            if self._pool is None:
+                from concurrent.futures import ThreadPoolExecutor
+                self._pool = ThreadPoolExecutor(max_workers=self.decode_threads, thread_name_prefix='clslam-png')
+            imgs = list(self._pool.map(self._decode_file, misses))
+        else:
+            imgs = [self._decode_file(k) for k in misses]
+        for k, img in zip(misses, imgs):
+            out[k] = self._keep(k, img)
+        return [out[k] for k in keys]
 
     def get_many(self, filenames, include_batch: bool = True, rng=None):
         """-> one dict per file, exactly the entries `_get(filename, include_batch)` returns."""
         import pickle
 
         import numpy as np
-        datas, raws, draws = [], [], []
+        datas, paths, draws = [], [], []
         for fn in filenames:
             # the jitter is drawn BEFORE the file is read (replay_buffer.py:264-268): same random stream as the reference
             draw = draw_color_jitter(rng=rng) if self.do_augmentation else None
@@ -204,10 +274,11 @@ class ReplaySampleBuilder:
                 data = pickle.load(f)
             datas.append(data)
             for frame in self.frames:
-                raws.append(self._decode(data['rgb', frame]))
+                paths.append(data['rgb', frame])
                 draws.append(draw)
-        if not raws:
+        if not paths:
             return []
+        raws = self._decode_all(paths)
         if len({tuple(r.shape) for r in raws}) != 1:
             raise _lib.ClslamError('replay samples with different raw image sizes in one batch')
         # one device staging block, one asynchronous copy per (page-locked) frame

@@ -5,7 +5,10 @@ slam/replay_buffer.py -- unchanged on top of the cl-slam_amd packages, with sys.
 documents it (cl-slam_amd/ ahead of the reference) and stubs only for the third-party packages the container
 lacks (tests/ref_stubs.py).  The HIP kernels run on the CPU emulator here.
 
-    python tests/ref_callers_driver.py <workdir> [frames]
+    python tests/ref_callers_driver.py <workdir> [frames] [gpu-ingest]
+
+`gpu-ingest`: the replay minibatch built by clslam_hip.ingest.ReplaySampleBuilder, switched on with its install() on the
+reference's ReplayBuffer / Slam OBJECTS (two instance attributes) -- the classes and every other line untouched.
 
 Prints one JSON line with what happened; tests/test_reference_callers.py asserts on it."""
 import json
@@ -55,6 +58,7 @@ def make_kitti_tree(root: Path, n: int, period: int) -> None:
 def main() -> None:
     work = Path(sys.argv[1])
     frames = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+    gpu_ingest = len(sys.argv) > 3 and sys.argv[3] == 'gpu-ingest'
     # --- the documented drop-in order: cl-slam_amd first, then the reference checkout ---------------------
     sys.path[:0] = [str(ROOT / 'cl-slam_amd'), str(REF)]
     sys.path += [str(TESTS), str(ROOT)]
@@ -116,7 +120,24 @@ def main() -> None:
     assert type(s.loop_closure_detection) is loop_closure_detection.LoopClosureDetection
     assert type(s.replay_buffer) is slam.replay_buffer.ReplayBuffer
     assert type(s.replay_buffer.feature_encoder) is loop_closure_detection.FeatureEncoder
-    report = {'origin': origin, 'steps': []}
+    report = {'origin': origin, 'steps': [], 'gpu_ingest': gpu_ingest}
+    if gpu_ingest:
+        from clslam_hip.ingest import ReplaySampleBuilder
+        rb = s.replay_buffer
+        builder = ReplaySampleBuilder(H, W, rb.scales, rb.frames, device=s.predictor.device, do_augmentation=rb.do_augmentation,
+                                      decode_threads=4)
+        builder.install(rb, s)
+        calls = {'get_many': 0, 'files': 0}
+        inner = builder.get_many
+
+        def counted(filenames, *a, **k):
+            calls['get_many'] += 1
+            calls['files'] += len(filenames)
+            return inner(filenames, *a, **k)
+        builder.get_many = counted
+        report['ingest_calls'] = calls
+    import random
+    random.seed(7)                                                    # the colour-jitter draws of the replay samples
     while s.current_step < frames:                                    # main_adapt.py:25-29
         losses = s.step()
         report['steps'].append({'step': s.current_step, 'loss': float(losses['depth_loss']),

@@ -39,3 +39,28 @@ def test_reference_slam_runs_unchanged_on_the_product_packages(tmp_path):
     assert rep['saved'] == ['depth_decoder.pth', 'depth_encoder.pth', 'optimizer.pth', 'pose_decoder.pth', 'pose_encoder.pth']
     assert rep['buffer_state'] and rep['reloaded_ids'] == steps[-1]['buffer']
     assert len(rep['replay_files']) == len(steps[-1]['buffer'])
+
+
+@pytest.mark.skipif(not REF.exists(), reason='the reference checkout only exists in the build container')
+def test_reference_slam_with_the_gpu_replay_ingest_installed(tmp_path):
+    """ReplaySampleBuilder.install(replay_buffer, slam) sets two instance attributes on the reference's own
+    objects (`get` / `_get` of its ReplayBuffer, `_cat_dict` of its Slam) and nothing else changes: the reference's `Slam.step` x4
+    runs on it, every replay minibatch is built by ONE get_many() call, and the frames' losses are those of the unpatched run
+    (same files, same jitter draws from Python's `random`, pyramid bit-exact, jitter <= 2e-6 -- tests/test_replay_ingest.py)."""
+    runs = {}
+    for mode in ('plain', 'gpu-ingest'):
+        work = tmp_path / mode
+        work.mkdir()
+        cmd = [sys.executable, str(DRIVER), str(work), '4'] + (['gpu-ingest'] if mode == 'gpu-ingest' else [])
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+        line = next(ln for ln in r.stdout.splitlines() if ln.startswith('REPORT '))
+        runs[mode] = json.loads(line[len('REPORT '):])
+    a, b = runs['plain'], runs['gpu-ingest']
+    assert b['gpu_ingest'] and not a['gpu_ingest']
+    assert b['ingest_calls']['get_many'] >= 3 and b['ingest_calls']['files'] >= b['ingest_calls']['get_many']
+    assert [s['buffer'] for s in a['steps']] == [s['buffer'] for s in b['steps']]
+    assert b['steps'][-1]['loop_closures'] == 1 and b['adam_steps'] == 4
+    for sa, sb in zip(a['steps'], b['steps']):
+        assert abs(sa['loss'] - sb['loss']) <= 2e-5 * abs(sa['loss']), (sa, sb)
+        assert abs(sa['velocity_loss'] - sb['velocity_loss']) <= 1e-5 * max(abs(sa['velocity_loss']), 1e-6), (sa, sb)

@@ -101,3 +101,30 @@ def test_replay_get_drop_in_matches_the_reference_get(backend, tmp_path):
     online = {k: v.cpu() for k, v in one_by_one[0].items()}
     cat = ingest.cat_dict(online, batched[1])
     assert cat['rgb', 0, 0].shape[0] == 2 and cat['rgb', 0, 0].device.type == dev.type
+
+
+def test_jitter_pin_script_is_honest():
+    """tests/golden/make_replay_jitter_golden.py pins oracle/jitter_tensor.py against the real torchvision the first time a build
+    container has it; until then it must say PARITY UNPINNED (exit 3) -- and once tests/golden/replay_jitter.npz exists the
+    restatement is held to torchvision's recorded outputs."""
+    import subprocess
+    import sys
+    gold = GOLDEN.parent / 'replay_jitter.npz'
+    try:
+        import torchvision  # noqa: F401
+        have_tv = True
+    except Exception:  # noqa: BLE001
+        have_tv = False
+    if not have_tv:
+        r = subprocess.run([sys.executable, str(GOLDEN.parent / 'make_replay_jitter_golden.py')], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 3 and 'PARITY UNPINNED' in r.stdout, r.stdout + r.stderr
+    if gold.exists():
+        from oracle import jitter_tensor as jt
+        sys.path.insert(0, str(GOLDEN.parent))
+        import make_replay_jitter_golden as mk
+        z = np.load(gold)
+        imgs = mk.images()
+        for order, factors, ref in zip(z['orders'], z['factors'], z['outputs']):
+            order = [int(o) for o in order if o >= 0]
+            got = torch.cat([jt.color_jitter(imgs[i:i + 1], order, list(factors)) for i in range(len(imgs))])
+            assert float((got - torch.from_numpy(ref)).abs().max()) <= 1e-6, (order, factors)

@@ -4,7 +4,7 @@
 # ranks compete for one GPU and gloo stages the 17.9 MB arena through host memory -- but the first run of that code on HIP streams.
 #   bash tools/dp2_gloo.sh > profiles/rNN_dp2_gloo.txt
 set -u
-brief() { python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print({k: d.get(k) for k in ('value', 'unit', 'ms_per_step', 'n_gpus')}, d['config']['shards'], d['config']['workload'][:60])"; }
+brief() { python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print({k: d.get(k) for k in ('value', 'unit', 'ms_per_step', 'n_gpus')}, d['config']['shards'], d['config']['workload'][:60]); ge = d.get('gradient_exchange'); [print('      exchange', r) for r in (ge['per_rank'] if ge else [])]"; }
 run() {  # label, env, bench args
     local label=$1; local envs=$2; shift 2
     echo "== $label ($envs)"

@@ -98,7 +98,8 @@ p = bench.build_predictor(H, W, 1 + K)
 p.optimizer.param_groups[0]['lr'] = 1e-6
 dev = p.device
 online_host = {k: v.pin_memory() for k, v in synth.make_batch(1, H, W, seed=3).items()}
-builders = {'gpu ingest': ingest.ReplaySampleBuilder(H, W, SCALES, FRAMES, dev),
+builders = {'gpu ingest, PNGs decoded in one thread': ingest.ReplaySampleBuilder(H, W, SCALES, FRAMES, dev, decode_threads=1),
+            'gpu ingest': ingest.ReplaySampleBuilder(H, W, SCALES, FRAMES, dev),            # 8 decode threads (default)
             'gpu ingest, decoded frames cached': ingest.ReplaySampleBuilder(H, W, SCALES, FRAMES, dev, cache_frames=3 * STORE)}
 pick = np.random.default_rng(1)
 
@@ -139,7 +140,7 @@ def frame(mode, detail=False):
 
 
 print(f'real frame @{H}x{W}, K = {K} replay samples from a store of {STORE} ({RAW_H}x{RAW_W} PNGs), {N} frames per mode')
-for mode in ('reference get (host)', 'gpu ingest', 'gpu ingest, decoded frames cached'):
+for mode in ('reference get (host)', 'gpu ingest, PNGs decoded in one thread', 'gpu ingest', 'gpu ingest, decoded frames cached'):
     random.seed(0)
     for _ in range(3 if mode == 'reference get (host)' else STORE):        # warm-up (and fill the decoded-frame cache)
         frame(mode)
