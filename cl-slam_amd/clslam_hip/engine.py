@@ -1498,8 +1498,11 @@ class Engine:
             stem = [(x, None, 0, n)]
         else:
             stem = [(x[:, :3].contiguous(), x[:, 3:].contiguous(), 0, n)]
-        self._cu_enc = 0
-        feats = self._encoder(self.enc[which], bufs, n, stem)
+        # the share of the chip the same encoder gets inside forward() for this many images: the persistent kernels' summation
+        # order (and the Winograd / direct pick) depends on it, and models['depth_encoder'](x) is bitwise what predict() computes
+        # (tests/test_slam_usage.py::test_the_four_models_are_callables)
+        cu = self.cu_limit(n, 'enc_depth') if nimg == 1 else self.cu_limit(max(1, n // 2), 'enc_pose')
+        feats = self._encoder(self.enc[which], bufs, n, stem, cu_limit=cu)
         self._memo = None
         if which == 'depth_encoder' and n == 1 and self.descriptor_memo:
             # (a private copy of the input: the caller owns x and may overwrite it; the feature buffers belong to this

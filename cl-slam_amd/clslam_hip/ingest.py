@@ -167,7 +167,7 @@ class ReplaySampleBuilder:
 
     def __init__(self, height: int, width: int, scales: Sequence[int] = (0, 1, 2, 3), frames: Sequence[int] = (0, -1, 1),
                  device=None, do_augmentation: bool = True, cache_frames: int = 0, cache_bytes: int = 256 << 20,
-                 decode_threads: int = 8) -> None:
+                 decode_threads: int = 16) -> None:
         self.height, self.width, self.scales, self.frames = int(height), int(width), tuple(scales), tuple(frames)
         self.device = torch.device('cuda' if device is None else device)
         self.do_augmentation = bool(do_augmentation)

@@ -95,4 +95,6 @@ def test_gradients_full_size_on_gpu(capsys, B):
     for name, e_free, e_forced, norm, e_all, e_hip64, e_o64, e_bwd, e_bwd_t32, e_bwd_p, e_bwd_p_t32 in r['rows']:
         assert e_free < lim['e_free'], (name, e_free)        # measured 2.5e-3 (B = 1) / 5.1e-2 (B = 5, 20 flipped selections)
         assert e_all < lim['e_all'], (name, e_all)           # the oracle's OWN forward, same selection / cells / clips: 1.1e-3 / 1.3e-2
-        assert e_bwd_p < FULL_SIZE_TOL[B], (name, e_bwd_p, e_bwd_p_t32, e_bwd, e_bwd_t32)
+        # ... or, where torch's OWN fp32 backward at that very point is no better (round 6, B = 5: pose_2.weight kernels 5.05e-4,
+        # torch fp32 5.08e-4 after the encoders' summation order changed with the 5/8 : 3/8 CU split), within 1.2x of torch's
+        assert e_bwd_p < max(FULL_SIZE_TOL[B], 1.2 * e_bwd_p_t32), (name, e_bwd_p, e_bwd_p_t32, e_bwd, e_bwd_t32)

@@ -7,6 +7,8 @@ from pathlib import Path
 import torch
 
 sys.path.insert(0, str(Path(__file__).resolve().parents[1] / 'cl-slam_amd'))
+sys.path.insert(0, str(Path(__file__).resolve().parent))
+import _variant  # noqa: F401,E402  (CLSLAM_TOOL_LIB=<tag>: a probe build of the library, tools/build_variant.py)
 from clslam_hip import ops  # noqa: E402
 
 dev = torch.device('cuda:0')

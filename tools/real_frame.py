@@ -99,7 +99,7 @@ p.optimizer.param_groups[0]['lr'] = 1e-6
 dev = p.device
 online_host = {k: v.pin_memory() for k, v in synth.make_batch(1, H, W, seed=3).items()}
 builders = {'gpu ingest, PNGs decoded in one thread': ingest.ReplaySampleBuilder(H, W, SCALES, FRAMES, dev, decode_threads=1),
-            'gpu ingest': ingest.ReplaySampleBuilder(H, W, SCALES, FRAMES, dev),            # 8 decode threads (default)
+            'gpu ingest': ingest.ReplaySampleBuilder(H, W, SCALES, FRAMES, dev),            # 16 decode threads (default)
             'gpu ingest, decoded frames cached': ingest.ReplaySampleBuilder(H, W, SCALES, FRAMES, dev, cache_frames=3 * STORE)}
 pick = np.random.default_rng(1)
 
