@@ -445,6 +445,9 @@ def main():
             pmc = json.load(open(ROOT / 'profiles' / 'pmc_traffic.json'))
             if pmc.get('_build_id') == build_id:
                 traffic = pmc[names[cfg]]['traffic_bytes_per_launch']
+                traffic_note = ('2 x FETCH_SIZE + WRITE_SIZE (MI355X_MICROARCH.md); calibrated in round 6 (profiles/r06_pmc_calibration.txt): '
+                                'FETCH_SIZE is exact, not half, for 64-B segment reads -- lower bound FETCH + WRITE = '
+                                f"{pmc[names[cfg]].get('traffic_bytes_per_launch_lower_bound')} bytes")
             else:
                 traffic_note = f"profiles/pmc_traffic.json was taken on build {pmc.get('_build_id')}, this is {build_id}"
         except Exception as e:

@@ -39,6 +39,11 @@ def main():
         fk, wk = sum(f[kn]) / len(f[kn]), sum(w[kn]) / len(w[kn])
         res[kn] = {'FETCH_SIZE_KB_avg': round(fk, 1), 'WRITE_SIZE_KB_avg': round(wk, 1), 'launches': len(f[kn]),
                    'traffic_bytes_per_launch': int((2 * fk + wk) * 1024),
+                   # round 6 calibration (tools/micro/pmc_calib.hip, profiles/r06_pmc_calibration.txt): WRITE_SIZE is exact for
+                   # coalesced, 64-B-segment and write-through stores; FETCH_SIZE is HALF the bytes of >= 128-B coalesced reads but
+                   # EXACT for 64-B segment reads (the 16-channel patch rows of a 64-channel layer) -- so the true L2-miss bytes of
+                   # a kernel that mixes both lie between FETCH + WRITE and 2 FETCH + WRITE
+                   'traffic_bytes_per_launch_lower_bound': int((fk + wk) * 1024),
                    'note': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tools/measure_round.sh, serial launch '
                            'order); FETCH_SIZE doubled per MI355X_MICROARCH.md; includes Infinity-Cache hits (L2-miss traffic)'}
     # identity of the kernel sources the counters were taken on (bench.py refuses to pair them with another build's timings)
