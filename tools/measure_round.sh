@@ -56,6 +56,19 @@ BENCH_WGRAD=1 python tools/bench_conv.py 5 30,31,32,33 > $OUT/${TAG}_conv_microb
 BENCH_WGRAD=0 python tools/bench_conv.py 1 30,31,32,33 > $OUT/${TAG}_conv_microbench_b1.txt 2>&1
 # Winograd F(2x2,3x3) (config 40) against the library's direct pick on the encoder layer shapes, B = 5 / 10 / 33
 { for b in 5 10 33; do echo "== B = $b"; BENCH_WGRAD=0 BENCH_LAYERS=0,1,2,3,8 python tools/bench_conv.py $b 40 2>&1 | grep -v amdgpu; done; } > $OUT/${TAG}_wino_microbench.txt
+# round 6: the END-TO-END frame (pinned host minibatch -> H2D inside adapt() -> pose + losses on the host) as a timeline with its copies
+rm -rf /tmp/prof_e2e
+(cd /tmp && rocprofv3 --kernel-trace --memory-copy-trace -d /tmp/prof_e2e -o run -- python $OLDPWD/tools/e2e_frames.py 12 4 > /tmp/prof_e2e.log 2>&1)
+python tools/timeline_e2e.py $(ls /tmp/prof_e2e/*/*.db /tmp/prof_e2e/*.db 2>/dev/null | head -1) -3 > $OUT/${TAG}_timeline_e2e.txt 2>&1
+python tools/e2e_frames.py 12 4 2>&1 | grep -v amdgpu > $OUT/${TAG}_e2e_host_stamps.txt
+# round 6: the Winograd kernel against batch size and workgroup count, and its per-wave phase times (probe build lib/variants/..._wtrace.so,
+# tools/build_variant.py wtrace conv_wino -DCLSLAM_WINO_TRACE=3 -- built in the container, travels with the snapshot)
+bash tools/wino_sweep.sh > $OUT/${TAG}_wino_sweep.txt 2>&1
+if [ -f cl-slam_amd/lib/variants/libclslam_hip_wtrace.so ]; then
+  { for args in "10 48 160 64 160" "5 48 160 64 96" "10 24 80 128 160" "10 6 20 512 160"; do CLSLAM_TOOL_LIB=wtrace python tools/wino_trace_waves.py $args 2>&1 | grep -v amdgpu; done; } > $OUT/${TAG}_wino_waves.txt
+fi
+# round 6: FETCH_SIZE / WRITE_SIZE against known byte counts in the Winograd kernel's access patterns
+bash tools/pmc_calib.sh > $OUT/${TAG}_pmc_calibration.txt 2>&1
 # gfx950 calibration the kernel designs rest on: MFMA vs same-wave / partner-wave VALU, LDS-DMA rate per CU
 { for m in mfma_clock mfma_valu_share lds_dma_rate event_gap ext_launch_cost; do echo "== tools/micro/$m.hip"; hipcc --offload-arch=gfx950 -O3 -o /tmp/$m tools/micro/$m.hip 2>/dev/null && /tmp/$m; done; } > $OUT/${TAG}_micro_calibration.txt 2>&1
 # one decoder-only step (steps 2..5 of adapt(steps=5)) as a kernel timeline
