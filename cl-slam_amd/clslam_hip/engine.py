@@ -133,6 +133,7 @@ class Engine:
         # orders the current stream behind the training step still in flight on the engine's own stream
         self._w = torch.zeros(n, device=device)
         self._wb_cache: Dict[str, Any] = {}
+        self._desc_cache: Dict[Any, Any] = {}     # conv descriptors of this engine's fixed call sites (ops.conv2d(cache=...))
         self._main = None
         self._g = torch.zeros(n, device=device)
         self._m = torch.zeros(n, device=device)
@@ -420,6 +421,7 @@ class Engine:
             self._w[off:off + flat.numel()].copy_(flat)
         self._packed_version = self._module_version()
         self._modules_stale = False
+        self._desc_cache.clear()               # re-laid-out weights / BN vectors: the kept descriptors point at the old ones
         for ws in self._ws.values():           # features of the previous encoder weights are void
             if hasattr(ws, 'frozen_valid'):
                 ws.frozen_valid = False
@@ -590,17 +592,17 @@ class Engine:
                         aux.wait_event(fork)
                         with self._on(aux):
                             ops.conv2d(x, blk.wd, res, scale=blk.sd, shift=blk.bd, ksize=1, stride=blk.stride, pad=0, act=ACT_NONE,
-                                       key=(ek, li, bi, 'd'))
+                                       cache=self._desc_cache, key=(ek, li, bi, 'd'))
                         joined.record(aux)
                 ops.conv2d(x, blk.w1, t, scale=blk.s1, shift=blk.b1, ksize=3, stride=blk.stride, act=ACT_RELU, weight_wino=blk.u1,
-                           key=(ek, li, bi, 1))
+                           cache=self._desc_cache, key=(ek, li, bi, 1))
                 if blk.wd is not None and joined is None:
                     ops.conv2d(x, blk.wd, res, scale=blk.sd, shift=blk.bd, ksize=1, stride=blk.stride, pad=0, act=ACT_NONE,
-                               key=(ek, li, bi, 'd'))
+                               cache=self._desc_cache, key=(ek, li, bi, 'd'))
                 if joined is not None:
                     stream.wait_event(joined)
                 ops.conv2d(t, blk.w2, y, scale=blk.s2, shift=blk.b2, residual=res, ksize=3, act=ACT_RELU, weight_wino=blk.u2,
-                           key=(ek, li, bi, 2))
+                           cache=self._desc_cache, key=(ek, li, bi, 2))
                 x = y
             feats.append(x)
         return feats
@@ -627,7 +629,7 @@ class Engine:
         for i in range(4, -1, -1):
             cin0 = NUM_CH_ENC[-1] if i == 4 else NUM_CH_DEC[i + 1]
             w, b = self._wb(f'depth_decoder/upconv_{i}_0.conv.conv', NUM_CH_DEC[i], cin0, 9)
-            ops.conv2d(x, w, ws.x[i, 0], shift=b, ksize=3, pad_mode=PAD_REFLECT, act=ACT_ELU, key=(id(self), 'dec', id(ws), i, 0))
+            ops.conv2d(x, w, ws.x[i, 0], shift=b, ksize=3, pad_mode=PAD_REFLECT, act=ACT_ELU, cache=self._desc_cache, key=(id(self), 'dec', id(ws), i, 0))
             skip = feats[i - 1] if i > 0 else None
             cin1 = NUM_CH_DEC[i] + (NUM_CH_ENC[i - 1] if i > 0 else 0)
             w, b = self._wb(f'depth_decoder/upconv_{i}_1.conv.conv', NUM_CH_DEC[i], cin1, 9)
@@ -636,7 +638,7 @@ class Engine:
             if ho is not None:
                 ho.arm()          # the leaf stream is released by this convolution's own completion signal
             ops.conv2d(ws.x[i, 0], w, ws.x[i, 1], src_b=skip, shift=b, ksize=3, pad_mode=PAD_REFLECT, upsample_a=True,
-                       act=ACT_ELU, key=None if skip is None else (id(self), 'dec', id(ws), i, 1, skip.data_ptr()))
+                       act=ACT_ELU, cache=self._desc_cache, key=None if skip is None else (id(self), 'dec', id(ws), i, 1, skip.data_ptr()))
             x = ws.x[i, 1]
             if i <= 3:
                 w, b = self._wb(f'depth_decoder/dispconv_{i}.conv', 1, NUM_CH_DEC[i], 9)
@@ -660,11 +662,11 @@ class Engine:
     def _pose_decoder(self, ws, f4: torch.Tensor) -> None:
         ops.PERSISTENT_CU_LIMIT = self._cu_dec
         w, b = self._wb('pose_decoder/squeeze', 256, 512, 1)
-        ops.conv2d(f4, w, ws.sq, shift=b, ksize=1, pad=0, act=ACT_RELU, key=(id(self), 'pdec', id(ws), 0))
+        ops.conv2d(f4, w, ws.sq, shift=b, ksize=1, pad=0, act=ACT_RELU, cache=self._desc_cache, key=(id(self), 'pdec', id(ws), 0))
         w, b = self._wb('pose_decoder/pose_0', 256, 256, 9)
-        ops.conv2d(ws.sq, w, ws.p0, shift=b, ksize=3, act=ACT_RELU, key=(id(self), 'pdec', id(ws), 1))
+        ops.conv2d(ws.sq, w, ws.p0, shift=b, ksize=3, act=ACT_RELU, cache=self._desc_cache, key=(id(self), 'pdec', id(ws), 1))
         w, b = self._wb('pose_decoder/pose_1', 256, 256, 9)
-        ops.conv2d(ws.p0, w, ws.p1, shift=b, ksize=3, act=ACT_RELU, key=(id(self), 'pdec', id(ws), 2))
+        ops.conv2d(ws.p0, w, ws.p1, shift=b, ksize=3, act=ACT_RELU, cache=self._desc_cache, key=(id(self), 'pdec', id(ws), 2))
         w, b = self._wb('pose_decoder/pose_2', 12, 256, 1)
         ops.pose_head_fwd(ws.p1, w.view(12, 256), b, ws.pmean, ws.pose)
 
@@ -1298,7 +1300,7 @@ class Engine:
                 dep='armed' if ho is not None else 'record')
             wt = t.wt_dec[i, 1]
             dxa = t.dxp[1][:B * (hi + 2) * (wi + 2) * ci].view(B, hi + 2, wi + 2, ci)
-            ops.conv2d(t.dz[i, 1], wt, dxa, ksize=3, pad=2, key=(id(self), 'dg', id(ws), i, 1))
+            ops.conv2d(t.dz[i, 1], wt, dxa, ksize=3, pad=2, cache=self._desc_cache, key=(id(self), 'dg', id(ws), i, 1))
             nb0 = ops.fold_blocks(B, hi, wi, ci, True)
             if ho is not None:
                 ho.arm()
@@ -1315,7 +1317,7 @@ class Engine:
             if i < 4:
                 wt = t.wt_dec[i, 0]
                 dxp_in = t.dxp[0][:B * (h2 + 2) * (w2 + 2) * cin0].view(B, h2 + 2, w2 + 2, cin0)
-                ops.conv2d(t.dz[i, 0], wt, dxp_in, ksize=3, pad=2, key=(id(self), 'dg', id(ws), i, 0))
+                ops.conv2d(t.dz[i, 0], wt, dxp_in, ksize=3, pad=2, cache=self._desc_cache, key=(id(self), 'dg', id(ws), i, 0))
             if i == 3 and mid_done is not None:
                 # every gradient of levels 0..3 and of the four disparity heads has been enqueued: weight gradients on the
                 # wgrad streams, bias partials by the folds on the main stream.  Level 4 (53 % of the arena) is still to come.
@@ -1341,10 +1343,10 @@ class Engine:
         self._wgrad(t, (ws.p0, None), (n2, h5, w5, 256), t.dz_p1, 'pose_decoder/pose_1', 256, 256, 9)
         # (transposed weights: _transpose_decoder_weights, issued at the start of backward())
         ops.conv2d(t.dz_p1, t.wt_pose[1], t.dz_p0, ksize=3, pad=1, actgrad_src=ws.p0, actgrad_kind=ACT_RELU,
-                   key=(id(self), 'pdg', id(ws), 1))
+                   cache=self._desc_cache, key=(id(self), 'pdg', id(ws), 1))
         self._wgrad(t, (ws.sq, None), (n2, h5, w5, 256), t.dz_p0, 'pose_decoder/pose_0', 256, 256, 9)
         ops.conv2d(t.dz_p0, t.wt_pose[0], t.dz_sq, ksize=3, pad=1, actgrad_src=ws.sq, actgrad_kind=ACT_RELU,
-                   key=(id(self), 'pdg', id(ws), 0))
+                   cache=self._desc_cache, key=(id(self), 'pdg', id(ws), 0))
         self._wgrad(t, (ws.pf4, None), (n2, h5, w5, 256), t.dz_sq, 'pose_decoder/squeeze', 256, 512, 1, pad=0)
 
     # ------------------------------------------------------------------------------------------

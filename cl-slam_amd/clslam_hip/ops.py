@@ -184,12 +184,17 @@ _DESC_CACHE_ON = __import__('os').environ.get('CLSLAM_DESC_CACHE', '1') != '0'
 
 def conv2d(src_a, weight, out, *, src_b=None, scale=None, shift=None, residual=None, ksize=3, stride=1,
            pad=None, pad_mode=PAD_ZERO, upsample_a=False, act=ACT_NONE, config=-1, actgrad_src=None,
-           actgrad_kind=ACT_NONE, workspace=None, weight_wino=None, cu_limit=None, key=None):
+           actgrad_kind=ACT_NONE, workspace=None, weight_wino=None, cu_limit=None, key=None, cache=None):
     """src_a (B,Ha,Wa,Ca) NHWC; weight (Cout, k*k, Ca+Cb); out (B,Ho,Wo,Cout); weight_wino: wino_weight_transform(weight).
     key (hashable, optional): identifies a FIXED call site -- same layer, same buffers, same keyword arguments every time;
-    its descriptor is kept and only stream-dependent fields (split-K scratch, cu_limit) are refreshed."""
+    its descriptor is kept and only stream-dependent fields (split-K scratch, cu_limit) are refreshed.
+    cache: the dict the descriptor lives in.  The engine passes its OWN (Engine._desc_cache): the entries then die with the
+    buffers they point into -- a module-global cache keyed by id() could hand a later engine, whose workspace happens to be
+    allocated at the same addresses, a descriptor with another geometry; the global one serves tests and tools."""
+    if cache is None:
+        cache = _CONV_DESC_CACHE
     if key is not None and PROFILE is None and _DESC_CACHE_ON:
-        ent = _CONV_DESC_CACHE.get(key)
+        ent = cache.get(key)
         if ent is not None:
             d, ref, lib = ent
             if d.src_a == src_a.data_ptr() and d.out == out.data_ptr() and d.weight == weight.data_ptr():
@@ -229,7 +234,7 @@ def conv2d(src_a, weight, out, *, src_b=None, scale=None, shift=None, residual=N
     lib = _lib.get_lib()
     lib.call('clslam_conv2d', C.byref(d), stream)
     if key is not None and PROFILE is None:
-        _CONV_DESC_CACHE[key] = (d, C.byref(d), lib)
+        cache[key] = (d, C.byref(d), lib)
     return out
 
 

@@ -426,7 +426,15 @@ extern "C" int clslam_conv2d(const clslam_conv_desc* d, void* stream_) {
     int cfg = d->config;
     const bool bk32 = (Cin % 32 == 0) && (d->ch_b == 0 || d->ch_a % 32 == 0);
     if (cfg < 0) cfg = clslam_conv2d_pick_config(d);
-    if (cfg == 40) return conv3x3_wino_dispatch(d, stream);
+    if (cfg == 40) {
+        const int rc = conv3x3_wino_dispatch(d, stream);
+        if (rc == CLSLAM_OK || d->config >= 0) return rc;
+        // an automatically picked Winograd launch that does not fit (scratch smaller than 64 KiB + one slab per workgroup): the
+        // direct kernels serve it, like an automatically picked stream-K configuration below
+        clslam_conv_desc tiled = *d;
+        tiled.config = -2;
+        cfg = clslam_conv2d_pick_config(&tiled);
+    }
     if (cfg >= 30) {
         const int rc = conv3x3_sk_dispatch(d, cfg, stream);
         if (rc == CLSLAM_OK || d->config >= 0) return rc;

@@ -87,7 +87,9 @@ typedef struct clslam_conv_desc {
     size_t workspace_bytes;
     /* Optional (ABI version >= 101): the same filter pre-transformed for the Winograd F(2x2,3x3) kernel by
      * clslam_wino_weight_transform (3x3, stride 1, zero padding, one source; needs `workspace`).  NULL: the direct kernels.
-     * Frozen weights (the two ResNet encoders) are transformed once per load; `weight` must still be set.              */
+     * Frozen weights (the two ResNet encoders) are transformed once per load; `weight` must still be set.  The kernel needs
+     * 64 KiB + 64 KiB per workgroup of `workspace` (hand-off flags -- eight per workgroup, holding the launch's epoch, never
+     * reset -- and one partial slab each); with config < 0 a launch that does not fit falls back to the direct kernels.   */
     const float* weight_wino;
     /* Optional (ABI version >= 102): how many compute units a PERSISTENT launch (the stream-K and Winograd kernels: one or two
      * resident workgroups per CU that walk the whole layer) may occupy; 0 = all of them.  A caller that runs independent

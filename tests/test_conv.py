@@ -284,6 +284,29 @@ def test_conv2d_winograd(backend, case, config, monkeypatch):
 
 
 @pytest.mark.parametrize('backend', BACKENDS)
+def test_auto_picked_winograd_falls_back_when_the_scratch_is_too_small(backend, monkeypatch):
+    """clslam_conv2d_pick_config returns the Winograd kernel whenever a scratch pointer and a transformed filter are
+    present; the kernel needs 64 KiB + 64 KiB per workgroup.  An AUTOMATICALLY picked Winograd launch that does not fit is served
+    by the direct kernels (like an automatically picked stream-K configuration); an explicitly requested one still fails."""
+    dev = use_backend(backend)
+    g = torch.Generator().manual_seed(23)
+    x = torch.randn(2, 12, 20, 64, generator=g)
+    w = torch.randn(64, 9, 64, generator=g) * 0.05
+    ref = _ref_conv(x, w, ksize=3, stride=1, pad=1, act=1)
+    t = lambda v: v.to(dev)   # noqa: E731
+    monkeypatch.setattr(ops, '_CONV_WORKSPACES', {})
+    u = ops.wino_weight_transform(t(w))
+    small = torch.zeros(96 << 10, dtype=torch.uint8, device=dev)          # flags + HALF a slab
+    d = ops.conv_desc(t(x), (2, 12, 20, 64), ksize=3)
+    out = torch.full((2, 12, 20, 64), float('nan'), device=dev)
+    ops.conv2d(t(x), t(w), out, ksize=3, act=1, workspace=small, weight_wino=u, cu_limit=2)
+    assert rel_err(out.cpu(), ref) < 2e-5
+    with pytest.raises(Exception, match='workspace'):
+        ops.conv2d(t(x), t(w), out, ksize=3, act=1, workspace=small, weight_wino=u, cu_limit=2, config=40)
+    del d
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
 def test_conv2d_call_site_descriptor_cache(backend):
     """conv2d(..., key=...): a fixed call site's descriptor is re-used only while source, weight and output sit where they sat --
     another tensor under the same key gets a descriptor of its own, the result is the uncached call's every time."""
