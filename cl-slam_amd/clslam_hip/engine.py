@@ -867,11 +867,12 @@ class Engine:
         else:
             self.wait_training()
             dfeats = (ws.dfeats if reuse else memo_feats if memo_feats is not None else
-                      self._encoder(self.enc['depth_encoder'], ws.denc, B, [(aug[0], None, 0, B)]))
+                      self._encoder(self.enc['depth_encoder'], ws.denc, B, [(aug[0], None, 0, B)], cu_limit=self._cu_depth))
             self._depth_decoder(ws, dfeats)
             pf4 = ws.pf4 if reuse else self._encoder(self.enc['pose_encoder'], ws.penc, 2 * B,
                                                      [(aug[-1], aug[0], 0, B), (aug[0], aug[1], B, B)],
-                                                     waits=None if inputs_ready is None else inputs_ready[1:3])[4]
+                                                     waits=None if inputs_ready is None else inputs_ready[1:3],
+                                                     cu_limit=self._cu_pose)[4]
             self._pose_decoder(ws, pf4)
         ws.dfeats, ws.pf4 = dfeats, pf4
         if defer_identity:
