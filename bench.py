@@ -463,6 +463,10 @@ def main():
             # `achieved` counts the ALGORITHMIC flops of the convolution (2 * M * Cout * 9 * Cin), as for every other
             # kernel; this kernel EXECUTES 16/36 of them on the matrix pipe -- both fractions are stated
             roof['algorithm'] = 'Winograd F(2x2,3x3): 16/36 of the direct MFMA count'
+            roof['pass_note'] = ('instrumented pass: serial launch order, every launch alone on the WHOLE chip (no cu_limit) -- there the depth '
+                                 "encoder's layer1-3 at 5 images fall below the kernel's 8 units per workgroup and run on the direct kernel; in "
+                                 'the TIMED step all 26 stride-1 3x3 encoder convolutions are Winograd launches, 13 on 5/8 of the chip (pose net) '
+                                 'beside 13 on 3/8 (depth net): profiles/r06_timeline_one_step.txt')
             roof['executed_mfma_tflops'] = round(fl / tt / 1e12 * 16 / 36, 2)
             roof['executed_mfma_frac'] = round(fl / tt / 1e12 * 16 / 36 / FP32_MFMA_PEAK_TFLOPS, 4)
         # the dominant DIRECT kernel beside it (rounds 1-4's roofline row), and how the launches split
