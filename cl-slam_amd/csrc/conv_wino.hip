@@ -64,7 +64,7 @@ struct WinoK {
     int B, Hi, Wi, Cin, Ho, Wo, Cout, pad, act;
     int RB, RH, RW;                      // region: RB images x RH x RW tiles of 2x2 outputs
     int regB, regY, regX, tilesN, tiles, NS, G;
-    long long units;
+    int units;                           // < 2^31 (checked by the dispatcher): 32-bit scalar arithmetic per unit
     float* slabs;                        // [G][kWinoSlabFloats]
     unsigned* flags;                     // [G]
     int b_fastest;
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino8_kernel(WinoK p) {
 #else
     const int grp = (int)blockIdx.x;
 #endif
-    const long long u0 = (long long)grp * p.units / p.G, u1 = (long long)(grp + 1) * p.units / p.G;
+    const int u0 = (int)((long long)grp * p.units / p.G), u1 = (int)((long long)(grp + 1) * p.units / p.G);
     if (u0 >= u1) return;
 #if CLSLAM_WINO_TRACE >= 3 && CLSLAM_DEVICE_BUILD
     // per-WAVE stamps ([G][8 waves][64] u64): start, prologue done, then per unit: input transform done, 16 positions done, finish()
@@ -195,13 +195,13 @@ __global__ __launch_bounds__(512) void conv3x3_wino8_kernel(WinoK p) {
     };
 
     struct Cur { int t, s, hi; };
-    auto seg_lo = [&](int t) { return (int)(max(u0, (long long)t * p.NS) - (long long)t * p.NS); };
-    auto seg_hi = [&](int t) { return (int)(min(u1, (long long)(t + 1) * p.NS) - (long long)t * p.NS); };
+    auto seg_lo = [&](int t) { return max(u0, t * p.NS) - t * p.NS; };
+    auto seg_hi = [&](int t) { return min(u1, (t + 1) * p.NS) - t * p.NS; };
     auto advance = [&](Cur& c) {
         if (++c.s >= c.hi) { --c.t; c.s = seg_lo(c.t); c.hi = seg_hi(c.t); }
     };
-    const int nunits = (int)(u1 - u0);
-    const int t_hi = (int)((u1 - 1) / p.NS);
+    const int nunits = u1 - u0;
+    const int t_hi = (u1 - 1) / p.NS;
 
     // ---- compute-side constants: this lane's operand slot is input channels 2*kg, 2*kg+1 of a stage -------------------------
     // U of a stage in LDS: [16 positions][4 groups of 16 output channels][4 input-channel pairs][16 channels][2] -- the 32 lanes the
@@ -267,8 +267,8 @@ __global__ __launch_bounds__(512) void conv3x3_wino8_kernel(WinoK p) {
             // Hand-offs are per WAVE: wave w of the owner adds exactly the slab rows wave w of a contributor wrote, so every wave
             // waits for its own eight flags and no workgroup barrier sits inside finish() (the two wave groups of a workgroup
             // reach it half a unit apart).  Flags hold the launch's epoch: nothing has to be reset.
-            const long long tile_first = (long long)t * p.NS;
-            for (int g2 = grp - 1; g2 >= 0 && (long long)(g2 + 1) * p.units / p.G > tile_first; --g2) ++ncon;
+            const int tile_first = t * p.NS;
+            for (int g2 = grp - 1; g2 >= 0 && (int)((long long)(g2 + 1) * p.units / p.G) > tile_first; --g2) ++ncon;
             float bad = 0.f;
             for (int c = lane; c < ncon; c += 64) {
                 unsigned spins = 0;
@@ -285,6 +285,9 @@ __global__ __launch_bounds__(512) void conv3x3_wino8_kernel(WinoK p) {
         const int oy = (ry * p.RH + ((tp >> 10) & 1023)) * 2, ox = (rx * p.RW + (tp & 1023)) * 2;
         const int nbase = tn * 64 + wn * 32 + 4 * kg;            // + 16 * nt
         const bool has_res = p.residual != nullptr;
+        // the kernel serves ReLU and identity epilogues only (conv3x3_wino_supported): one v_max per element instead of the five-way
+        // activation switch (expm1f and all) compiled 32 times into finish()
+        const float act_floor = p.act == CLSLAM_ACT_RELU ? 0.f : -__builtin_inff();
         bool pix_ok[4];
         unsigned opix[4];                  // element offsets fit 32 bits (checked by the dispatcher): four registers, not eight
 #pragma unroll
@@ -345,7 +348,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino8_kernel(WinoK p) {
             for (int y = 0; y < 4; ++y) {
                 float4 v = make_float4(Y[y][0] * sc.x + sh.x, Y[y][1] * sc.y + sh.y, Y[y][2] * sc.z + sh.z, Y[y][3] * sc.w + sh.w);
                 v.x += ex[y].x; v.y += ex[y].y; v.z += ex[y].z; v.w += ex[y].w;
-                v.x = apply_act(v.x, p.act); v.y = apply_act(v.y, p.act); v.z = apply_act(v.z, p.act); v.w = apply_act(v.w, p.act);
+                v.x = fmaxf(v.x, act_floor); v.y = fmaxf(v.y, act_floor); v.z = fmaxf(v.z, act_floor); v.w = fmaxf(v.w, act_floor);
                 outv[y][n] = v;
             }
         }
@@ -536,6 +539,7 @@ static void wino_pick_region(int B, int Ho, int Wo, int& RB, int& RH, int& RW) {
 int conv3x3_wino_supported(const clslam_conv_desc* d) {
     return d->weight_wino != nullptr && d->ksize == 3 && d->stride == 1 && d->ch_b == 0 && !d->upsample_a && d->pad_mode == CLSLAM_PAD_ZERO &&
            d->ch_a % 16 == 0 && d->ch_out % 16 == 0 && (d->pad == 1 || d->pad == 2) && d->actgrad_src == nullptr &&
+           (d->act == CLSLAM_ACT_NONE || d->act == CLSLAM_ACT_RELU) &&
            d->out_h == d->in_h + 2 * d->pad - 2 && d->out_w == d->in_w + 2 * d->pad - 2;
 }
 
@@ -581,10 +585,11 @@ int conv3x3_wino_dispatch(const clslam_conv_desc* d, hipStream_t stream) {
     k.tilesN = cdiv(k.Cout, 64);
     k.tiles = k.regB * k.regY * k.regX * k.tilesN;
     k.NS = k.Cin / 8;
-    k.units = (long long)k.tiles * k.NS;
+    if ((long long)k.tiles * k.NS >= (1ll << 31)) { set_error("conv2d: too many (region, stage) units for the Winograd kernel"); return CLSLAM_ERR_INVALID; }
+    k.units = k.tiles * k.NS;
     k.b_fastest = ((size_t)k.Cout * 16 * k.Cin > (size_t)k.B * k.Hi * k.Wi * k.Cin) ? 1 : 0;
     if (const char* e = getenv("CLSLAM_SK_B_FASTEST")) k.b_fastest = atoi(e);
-    const int G = (int)std::min<long long>(wino_groups(d), k.units);
+    const int G = std::min(wino_groups(d), k.units);
     k.G = G;
     const size_t need = (size_t)kWinoSlabOffsetBytes + (size_t)G * kWinoSlabFloats * sizeof(float) + (CLSLAM_WINO_TRACE ? (size_t)G * 64 * 8 * (CLSLAM_WINO_TRACE >= 3 ? 8 : 1) : 0);
     if (!d->workspace || d->workspace_bytes < need) {
