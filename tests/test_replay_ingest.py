@@ -128,3 +128,73 @@ def test_jitter_pin_script_is_honest():
             order = [int(o) for o in order if o >= 0]
             got = torch.cat([jt.color_jitter(imgs[i:i + 1], order, list(factors)) for i in range(len(imgs))])
             assert float((got - torch.from_numpy(ref)).abs().max()) <= 1e-6, (order, factors)
+
+
+class _BufferShapedLikeTheReference:
+    """The three members of slam/replay_buffer.py's ReplayBuffer that install() touches, with the reference's calling pattern:
+    `get` chooses files, calls `self._get(filename)` once per file and concatenates the dicts key by key (replay_buffer.py:226-233)."""
+
+    def __init__(self, files, host_get):
+        self.files, self._host_get, self.calls = files, host_get, 0
+
+    def _get(self, filename, include_batch=True):
+        self.calls += 1
+        return self._host_get(filename)
+
+    def get(self, sample, image_features=None):
+        data = self._get(self.files[0])
+        for fn in self.files[1:]:
+            nxt = self._get(fn)
+            for key in data:
+                data[key] = torch.cat([data[key], nxt[key]])
+        return data
+
+
+class _SlamShapedLikeTheReference:
+    @staticmethod
+    def _cat_dict(a, b):                 # slam/slam.py:300-309
+        return {k: torch.cat([a[k], b[k]]) for k in a if k in b}
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_install_switches_a_replay_buffer_and_a_slam_object_over(backend, tmp_path):
+    """install() on objects with the reference's calling pattern (the reference itself runs in tests/test_reference_callers.py, build
+    container only; this twin also runs on the MI355X): `get` builds the K samples in ONE get_many() -- bitwise what get_many()
+    returns for those files with the same `random` state --, the object's own `_get` is never entered, `_cat_dict` joins a host
+    sample with the device minibatch, and the classes are untouched (another instance still runs its own code)."""
+    from PIL import Image
+    dev = use_backend(backend)
+    z = np.load(GOLDEN, allow_pickle=False)
+    H, W, scales, frames = int(z['height']), int(z['width']), [int(s) for s in z['scales']], [int(f) for f in z['frames']]
+    files = []
+    for i in range(int(z['n_samples'])):
+        sample = {('camera_matrix', 0): torch.from_numpy(z['camera_matrix']).clone(), ('index',): torch.tensor([i])}
+        for f in frames:
+            png = tmp_path / f's{i}_f{f}.png'
+            Image.fromarray(z[f'raw_{i}_{f}']).save(png)
+            sample['rgb', f] = png
+        fn = tmp_path / f'kitti_{i:05}.pkl'
+        with open(fn, 'wb') as fh:
+            pickle.dump(sample, fh)
+        files.append(fn)
+    build = ingest.ReplaySampleBuilder(H, W, scales, frames, device=dev, decode_threads=4)
+    random.seed(11)
+    want = build.get_many(files)
+    want = {k: torch.cat([d[k] for d in want]) for k in want[0]}
+    buf, slam = _BufferShapedLikeTheReference(files, host_get=None), _SlamShapedLikeTheReference()
+    assert build.install(buf, slam) is build
+    random.seed(11)
+    got = buf.get({'index': torch.tensor([0])})
+    assert buf.calls == 0 and set(got) == set(want)
+    for k in want:
+        assert torch.equal(got[k].cpu(), want[k].cpu()) and got[k].device == want[k].device, k
+    assert got['rgb_aug', 0, 0].device.type == dev.type and got['rgb_aug', 0, 0].shape[0] == len(files)
+    online = {k: v[:1].cpu() for k, v in got.items()}
+    joined = slam._cat_dict(online, got)
+    assert joined['rgb', 0, 0].shape[0] == len(files) + 1 and joined['rgb', 0, 0].device.type == dev.type
+    assert torch.equal(joined['rgb', 0, 0][1:].cpu(), got['rgb', 0, 0].cpu())
+    # direct callers of _get get the builder's, too; the CLASS keeps its own code
+    one = buf._get(files[0])
+    assert one['rgb', 0, 0].device.type == dev.type and buf.calls == 0
+    other = _BufferShapedLikeTheReference(files[:1], host_get=lambda fn: {'x': torch.zeros(1)})
+    assert set(other.get(None)) == {'x'} and other.calls == 1
